@@ -1,0 +1,165 @@
+"""ctypes front end of the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see oracle/sgbm_oracle.h for what is restated and the "parity unpinned" statement).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle_sgbm.so")
+
+
+class Params(C.Structure):
+    # keyword arguments of cv2.StereoSGBM_create, /root/reference/main.ipynb:655-666
+    _fields_ = [(n, C.c_int32) for n in (
+        "minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff",
+        "preFilterCap", "uniquenessRatio", "speckleWindowSize", "speckleRange", "mode")]
+
+
+class Taps(C.Structure):
+    _fields_ = [("C", C.c_void_p), ("S", C.c_void_p), ("disp_raw", C.c_void_p),
+                ("disp_median", C.c_void_p), ("max_cost_plus_p2", C.c_int32),
+                ("max_delta", C.c_int32), ("headroom_ok", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("sgbm_oracle.c", "sgbm_oracle.h")]
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "liboracle_sgbm.so"],
+                       check=True, capture_output=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.oracle_sgbm_compute.restype = C.c_int
+        L.oracle_sgbm_compute.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_int64, C.c_void_p, C.POINTER(Taps)]
+        L.oracle_sgbm_geometry.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int)]
+        L.oracle_median3x3_i16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.oracle_filter_speckles_i16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int]
+        L.oracle_disp_to_float.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.oracle_reproject_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_void_p]
+        L.oracle_valid_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def make_params(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0,
+                preFilterCap=0, uniquenessRatio=0, speckleWindowSize=0, speckleRange=0,
+                mode=0) -> Params:
+    """Defaults are those of cv2.StereoSGBM_create (OpenCV 4.11 signature)."""
+    return Params(minDisparity, numDisparities, blockSize, P1, P2, disp12MaxDiff, preFilterCap,
+                  uniquenessRatio, speckleWindowSize, speckleRange, mode)
+
+
+def geometry(p: Params, W: int):
+    a, b = C.c_int(), C.c_int()
+    lib().oracle_sgbm_geometry(C.byref(p), W, C.byref(a), C.byref(b))
+    return a.value, b.value  # minX1, W1
+
+
+def sgbm_compute(left: np.ndarray, right: np.ndarray, taps: bool = False, **kw):
+    """stereo.compute(left, right) of main.ipynb:668 -> int16 (H, W).
+
+    With taps=True also returns a dict with C, S, disp_raw, disp_median and the headroom record.
+    """
+    p = kw.pop("params", None) or make_params(**kw)
+    left = np.ascontiguousarray(left, dtype=np.uint8)
+    right = np.ascontiguousarray(right, dtype=np.uint8)
+    assert left.ndim == 2 and left.shape == right.shape
+    H, W = left.shape
+    disp = np.empty((H, W), np.int16)
+    t = Taps()
+    out = {}
+    if taps:
+        _, W1 = geometry(p, W)
+        D = p.numDisparities
+        if W1 > 0:
+            out["C"] = np.zeros((H, W1, D), np.int16)
+            out["S"] = np.zeros((H, W1, D), np.int16)
+            t.C = out["C"].ctypes.data
+            t.S = out["S"].ctypes.data
+        out["disp_raw"] = np.empty((H, W), np.int16)
+        out["disp_median"] = np.empty((H, W), np.int16)
+        t.disp_raw = out["disp_raw"].ctypes.data
+        t.disp_median = out["disp_median"].ctypes.data
+    rc = lib().oracle_sgbm_compute(C.byref(p), left.ctypes.data, right.ctypes.data, H, W,
+                                   left.strides[0], disp.ctypes.data, C.byref(t))
+    if rc != 0:
+        raise ValueError(f"oracle_sgbm_compute failed rc={rc}")
+    if taps:
+        out.update(max_cost_plus_p2=t.max_cost_plus_p2, max_delta=t.max_delta,
+                   headroom_ok=bool(t.headroom_ok))
+        return disp, out
+    return disp
+
+
+def headroom_ok(left, right, **kw) -> bool:
+    p = kw.pop("params", None) or make_params(**kw)
+    left = np.ascontiguousarray(left, dtype=np.uint8)
+    right = np.ascontiguousarray(right, dtype=np.uint8)
+    H, W = left.shape
+    disp = np.empty((H, W), np.int16)
+    t = Taps()
+    rc = lib().oracle_sgbm_compute(C.byref(p), left.ctypes.data, right.ctypes.data, H, W,
+                                   left.strides[0], disp.ctypes.data, C.byref(t))
+    assert rc == 0
+    return bool(t.headroom_ok)
+
+
+def median3x3(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, dtype=np.int16)
+    out = np.empty_like(img)
+    lib().oracle_median3x3_i16(img.ctypes.data, out.ctypes.data, img.shape[0], img.shape[1])
+    return out
+
+
+def filter_speckles(img: np.ndarray, newVal: int, maxSpeckleSize: int, maxDiff: int) -> np.ndarray:
+    out = np.array(img, dtype=np.int16, order="C", copy=True)
+    lib().oracle_filter_speckles_i16(out.ctypes.data, out.shape[0], out.shape[1], newVal,
+                                     maxSpeckleSize, maxDiff)
+    return out
+
+
+def disp_to_float(disp: np.ndarray) -> np.ndarray:
+    disp = np.ascontiguousarray(disp, dtype=np.int16)
+    out = np.empty(disp.shape, np.float32)
+    lib().oracle_disp_to_float(disp.ctypes.data, out.ctypes.data, disp.size)
+    return out
+
+
+def reproject(disp: np.ndarray, Q: np.ndarray, handle_missing: bool = False) -> np.ndarray:
+    disp = np.ascontiguousarray(disp, dtype=np.float32)
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    assert Q.shape == (4, 4)
+    H, W = disp.shape
+    out = np.empty((H, W, 3), np.float32)
+    lib().oracle_reproject_f32(disp.ctypes.data, H, W, Q.ctypes.data, int(handle_missing),
+                               out.ctypes.data)
+    return out
+
+
+def valid_mask(xyz: np.ndarray, disp: np.ndarray) -> np.ndarray:
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    disp = np.ascontiguousarray(disp, dtype=np.float32)
+    out = np.empty(disp.shape, np.uint8)
+    lib().oracle_valid_mask(xyz.ctypes.data, disp.ctypes.data, disp.size, out.ctypes.data)
+    return out.astype(bool)

@@ -1,0 +1,140 @@
+"""Implementation-independent known answers for the CPU oracle.
+
+The reference holds no fixtures for this path ("parity unpinned"); these anchor the oracle to
+the specification with cases whose answer can be derived by hand.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from stereo_reconstruction_cv_amd import synth
+
+NB = dict(disp12MaxDiff=1, preFilterCap=63, uniquenessRatio=10, speckleWindowSize=100, speckleRange=32)
+
+
+def nb_params(D, bs, **kw):
+    d = dict(minDisparity=0, numDisparities=D, blockSize=bs, P1=8 * 3 * bs * bs, P2=32 * 3 * bs * bs, **NB)
+    d.update(kw)
+    return d
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_constant_image_gives_zero_disparity(mode):
+    img = np.full((40, 64), 100, np.uint8)
+    d = O.sgbm_compute(img, img, numDisparities=16, blockSize=3, mode=mode)
+    assert (d[:, :16] == -16).all()          # columns [0, D) can never be matched
+    assert (d[:, 16:] == 0).all()            # all costs 0 -> first minimum -> d = 0
+
+
+@pytest.mark.parametrize("k", [1, 5, 11])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pure_shift(k, mode):
+    base = synth.texture(64, 192, 5).astype(np.uint8)
+    right = np.roll(base, -k, axis=1)
+    d = O.sgbm_compute(base, right, mode=mode, **nb_params(16, 5, P1=200, P2=800))
+    inner = d[12:52, 48:160]
+    # the parabola fit may move the answer by 1/16 px where neighbours' costs are asymmetric
+    assert (np.abs(inner.astype(int) - 16 * k) <= 1).all()
+    assert (inner == 16 * k).mean() > 0.9
+
+
+def test_width_not_larger_than_disparity_range_is_all_invalid():
+    img = np.zeros((8, 16), np.uint8)
+    d = O.sgbm_compute(img, img, numDisparities=16, blockSize=3)
+    assert (d == -16).all()
+    d = O.sgbm_compute(img, img, numDisparities=16, minDisparity=4, blockSize=3)
+    assert (d == 48).all()                   # (minD - 1) * 16
+
+
+def test_median_by_hand():
+    a = np.array([[1, 9, 3], [7, 5, 8], [2, 6, 4]], np.int16)
+    m = O.median3x3(a)
+    assert m[1, 1] == 5
+    # corner (0,0): replicate border -> {1,1,9,1,1,9,7,7,5} sorted 1,1,1,1,5,7,7,9,9 -> 5
+    assert m[0, 0] == 5
+    # single column degenerates to a 1-D median of three
+    c = np.array([[5], [1], [9], [3]], np.int16)
+    assert O.median3x3(c).ravel().tolist() == [5, 5, 3, 3]
+    # -16 is an ordinary value
+    b = np.full((3, 3), -16, np.int16); b[1, 1] = 100
+    assert (O.median3x3(b) == -16).all()
+
+
+def test_speckle_by_hand():
+    img = np.full((8, 10), -16, np.int16)
+    img[1:3, 1:3] = 160           # 4-pixel blob  -> removed when maxSpeckleSize >= 4
+    img[4:8, 4:9] = 320           # 20-pixel blob -> kept when maxSpeckleSize < 20
+    img[4, 4] = 320 + 17          # still linked with maxDiff 17
+    img[0, 9] = 800               # isolated pixel
+    out = O.filter_speckles(img, -16, 4, 17)
+    assert (out[1:3, 1:3] == -16).all() and out[0, 9] == -16
+    assert (out[4:8, 4:9] != -16).all()
+    out = O.filter_speckles(img, -16, 3, 17)
+    assert (out[1:3, 1:3] == 160).all()
+    # the link threshold is inclusive and splits components when exceeded
+    img2 = np.array([[0, 16, 33, 49]], np.int16)
+    assert O.filter_speckles(img2, -16, 2, 16).tolist() == [[-16, -16, -16, -16]]
+    assert O.filter_speckles(img2, -16, 1, 16).tolist() == [[0, 16, 33, 49]]
+    # diagonal neighbours are not connected
+    img3 = np.array([[5, -16], [-16, 5]], np.int16)
+    assert (O.filter_speckles(img3, -16, 1, 100) == -16).all()
+
+
+def test_disp_to_float_signs():
+    d = np.array([[-16, 0, 1, 33]], np.int16)
+    f = O.disp_to_float(d)
+    assert f.tolist() == [[-0.0, 0.0, 1 / 16, 33 / 16]]
+    assert np.signbit(f[0, 0]) and not np.signbit(f[0, 1])       # main.ipynb:669-670
+
+
+def test_reproject_by_hand():
+    Q = synth.default_Q(3840)
+    disp = np.array([[0.0, 2.0], [4.0, -0.0]], np.float32)
+    xyz = O.reproject(disp, Q)
+    # (x=1, y=0, d=2): W = -d = -2 ; X = (1 - cx)/W etc.
+    cx, cy, f = 1909.9754, 1057.74529, 2045.48384
+    exp = np.array([(1 - cx) / -2.0, (0 - cy) / -2.0, f / -2.0])
+    assert np.allclose(xyz[0, 1], exp, rtol=1e-6)
+    exp = np.array([(0 - cx) / -4.0, (1 - cy) / -4.0, f / -4.0])
+    assert np.allclose(xyz[1, 0], exp, rtol=1e-6)
+    assert not np.isfinite(xyz[0, 0]).any() and not np.isfinite(xyz[1, 1]).any()
+    m = O.valid_mask(xyz, disp)
+    assert m.tolist() == [[False, True], [True, False]]
+    # handleMissingValues: pixels at the map minimum get Z = 10000
+    xyz2 = O.reproject(np.array([[1.0, 3.0]], np.float32), Q, True)
+    assert xyz2[0, 0, 2] == 10000.0 and xyz2[0, 1, 2] != 10000.0
+
+
+def test_single_pixel_cost_by_hand():
+    # 1 x 6 image, D = 2, blockSize 1: the block cost is the pixel cost; check one entry.
+    L = np.array([[10, 20, 40, 80, 60, 30]], np.uint8)
+    R = np.array([[12, 22, 44, 70, 50, 20]], np.uint8)
+    _, t = O.sgbm_compute(L, R, taps=True, numDisparities=2, blockSize=1, preFilterCap=63)
+    C = t["C"]                                  # [1][W1=4][2], first valid column x = 2
+    # x = 3, d = 1 -> right column 2.  H = 1 so up/down rows are the row itself:
+    # gradient channel: pf = clip(4*(I[x+1]-I[x-1]), -63, 63) + 63
+    pfL = [63] + [int(np.clip(4 * (int(L[0, i + 1]) - int(L[0, i - 1])), -63, 63)) + 63 for i in range(1, 5)] + [63]
+    pfR = [63] + [int(np.clip(4 * (int(R[0, i + 1]) - int(R[0, i - 1])), -63, 63)) + 63 for i in range(1, 5)] + [63]
+    rawL = [63] + L[0, 1:5].tolist() + [63]
+    rawR = [63] + R[0, 1:5].tolist() + [63]
+
+    def bt(a, b, x, xr):
+        u, v = a[x], b[xr]
+        ul, ur = (u + a[x - 1]) // 2, (u + a[x + 1]) // 2
+        vl, vr = (v + b[xr - 1]) // 2, (v + b[xr + 1]) // 2
+        u0, u1, v0, v1 = min(u, ul, ur), max(u, ul, ur), min(v, vl, vr), max(v, vl, vr)
+        return min(max(0, u - v1, v0 - u), max(0, v - u1, u0 - v))
+
+    exp = bt(pfL, pfR, 3, 2) + (bt(rawL, rawR, 3, 2) >> 2)
+    assert C[0, 3 - 2, 1] == exp
+
+
+def test_headroom_flag():
+    l, r, _ = synth.make_pair(48, 128, 32, 9)
+    assert O.headroom_ok(l, r, **nb_params(32, 7, P1=1176, P2=4704))
+    # constant 0 vs constant 255: raw-channel cost 255 >> 2 = 63 per pixel, C = 63 * 49 = 3087;
+    # with P2 = 30000 upstream's int16 lane holding C + P2 would overflow
+    a = np.zeros((24, 64), np.uint8)
+    b = np.full((24, 64), 255, np.uint8)
+    _, t = O.sgbm_compute(a, b, taps=True, numDisparities=16, blockSize=7, P1=10, P2=30000)
+    assert t["max_cost_plus_p2"] == 3087 + 30000 and not t["headroom_ok"]
