@@ -137,4 +137,5 @@ def test_headroom_flag():
     a = np.zeros((24, 64), np.uint8)
     b = np.full((24, 64), 255, np.uint8)
     _, t = O.sgbm_compute(a, b, taps=True, numDisparities=16, blockSize=7, P1=10, P2=30000)
-    assert t["max_cost_plus_p2"] == 3087 + 30000 and not t["headroom_ok"]
+    # (the tracked maximum includes the running-sum intermediate C(y-1) + hsum(y+3) = 3087 + 441)
+    assert t["max_cost_plus_p2"] == 3087 + 441 + 30000 and not t["headroom_ok"]
