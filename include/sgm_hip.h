@@ -1,0 +1,131 @@
+/*
+ * sgm_hip.h -- C ABI of the MI355X (gfx950) dense stereo disparity engine.
+ *
+ * Drop-in boundary for the reference's "Run Disparity" path.  The reference has no FFI of its
+ * own for this path: the boundary is the cv2 Python API at three call sites, and each entry
+ * point below names the call it replaces (file:line in /root/reference):
+ *
+ *   sgm_create           <- cv2.StereoSGBM_create(minDisparity=..., ...)      main.ipynb:655-666
+ *   sgm_compute          <- stereo.compute(imgL, imgR)  -> int16 HxW          main.ipynb:668
+ *   sgm_disp_to_float    <- .astype(np.float32)/16 ; mask = >0 ; multiply      main.ipynb:668-670
+ *   sgm_reproject        <- cv2.reprojectImageTo3D(disparity_map, Q)           main.ipynb:697
+ *   sgm_valid_mask       <- ~isnan(X) & ~isinf(X) & (disparity_map > 0)        main.ipynb:726-730
+ *   sgm_pipeline_device  <- cell c13: compute -> scale/mask -> reproject       main.ipynb:781,790
+ *   sgm_compute_batch    <- the same, over N independent pairs (frame sharding unit)
+ *
+ * Conventions: plain pointers and sizes, no C++ types, no exceptions across the boundary.
+ * Every function returns 0 on success or a negative sgm_status; sgm_last_error() returns a
+ * thread-local message.  All host buffers are caller-owned; device memory lives in the engine
+ * and is reused between calls (regrown on shape change).  An engine is bound to one GPU and
+ * one HIP stream and is not thread-safe: one engine per thread / GPU.  Host-pointer entry
+ * points block until the result is in the caller's buffer (the notebook / Tk call shape);
+ * *_device entry points take device pointers, enqueue on the given stream and return.
+ * There is NO CPU fallback: without a usable GPU sgm_create fails with SGM_ERR_NO_DEVICE.
+ */
+#ifndef SGM_HIP_H
+#define SGM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGM_ABI_VERSION 1
+
+typedef enum {
+    SGM_OK = 0,
+    SGM_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, unsupported parameter       */
+    SGM_ERR_NO_DEVICE = -2,     /* no HIP device / device index out of range                     */
+    SGM_ERR_HIP = -3,           /* a HIP runtime call failed; message has the hipError string    */
+    SGM_ERR_UNSUPPORTED = -4,   /* mode 2/3 (3WAY/HH4), numDisparities not a multiple of 16, ... */
+    SGM_ERR_NOMEM = -5
+} sgm_status;
+
+/* keyword arguments of cv2.StereoSGBM_create (main.ipynb:655-666); mode: 0 = MODE_SGBM
+ * (5 paths, what the notebook runs), 1 = MODE_HH (8 paths).  Zero / negative values are
+ * normalised exactly as OpenCV 4.11 does. */
+typedef struct {
+    int32_t minDisparity;
+    int32_t numDisparities;
+    int32_t blockSize;
+    int32_t P1;
+    int32_t P2;
+    int32_t disp12MaxDiff;
+    int32_t preFilterCap;
+    int32_t uniquenessRatio;
+    int32_t speckleWindowSize;
+    int32_t speckleRange;
+    int32_t mode;
+} sgm_params;
+
+typedef struct sgm_engine sgm_engine; /* opaque */
+
+/* stage taps of the last sgm_compute*: device buffers copied to host for the parity tests */
+typedef enum {
+    SGM_TAP_COST = 0,        /* int16 [H][W1][D]  block cost C (without upstream's +P2 bias)     */
+    SGM_TAP_AGGR = 1,        /* int16 [H][W1][D]  aggregated cost S (needs sgm_set_option KEEP)  */
+    SGM_TAP_DISP_RAW = 2,    /* int16 [H][W]      after WTA / uniqueness / sub-pixel / LR check  */
+    SGM_TAP_DISP_MEDIAN = 3  /* int16 [H][W]      after the 3x3 median                           */
+} sgm_tap;
+
+typedef enum {
+    SGM_OPT_KEEP_AGGR = 0,   /* 1: the last path kernel also stores S (debug; costs bandwidth)   */
+    SGM_OPT_PROFILE = 1      /* 1: bracket every stage with HIP events on the engine's stream    */
+} sgm_option;
+
+#define SGM_MAX_STAGES 32
+typedef struct {
+    int32_t n;                         /* number of stages recorded by the last compute        */
+    const char *name[SGM_MAX_STAGES];  /* static strings                                       */
+    float ms[SGM_MAX_STAGES];          /* HIP-event elapsed time of each stage                 */
+    int32_t launches[SGM_MAX_STAGES];  /* kernel launches inside the stage                     */
+} sgm_stage_times;
+
+int sgm_abi_version(void);
+int sgm_device_count(void);
+const char *sgm_last_error(void);
+
+/* stream: a hipStream_t passed as void*, or NULL to let the engine create its own. */
+int sgm_create(const sgm_params *params, int device_id, void *stream, sgm_engine **out);
+void sgm_destroy(sgm_engine *e);
+int sgm_set_option(sgm_engine *e, int option, int value);
+
+/* geometry: W1 = number of columns that can be matched, minX1 = first such column */
+int sgm_geometry(const sgm_params *params, int W, int *minX1, int *W1);
+
+/* ---- host-pointer entry points (blocking) ---- */
+int sgm_compute(sgm_engine *e, const uint8_t *left, const uint8_t *right, int H, int W,
+                int64_t stride_bytes, int16_t *disp_out /* H*W */);
+int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t *rights, int H,
+                      int W, int16_t *disps_out /* N*H*W */, float *xyz_out /* N*H*W*3 or NULL */,
+                      const double *Q16 /* needed iff xyz_out */);
+int sgm_disp_to_float(sgm_engine *e, const int16_t *disp, int64_t n, float *out);
+int sgm_reproject(sgm_engine *e, const float *disp, int H, int W, const double Q[16],
+                  int handle_missing, float *xyz_out /* H*W*3 */);
+int sgm_valid_mask(sgm_engine *e, const float *xyz, const float *disp, int64_t n, uint8_t *mask);
+int sgm_get_tap(sgm_engine *e, int tap, void *host_dst, int64_t bytes);
+
+/* ---- device-pointer entry points (asynchronous on the engine's stream) ---- */
+int sgm_compute_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W,
+                       int64_t stride_bytes, void *d_disp_i16);
+int sgm_disp_to_float_device(sgm_engine *e, const void *d_disp_i16, int64_t n, void *d_out_f32);
+int sgm_reproject_device(sgm_engine *e, const void *d_disp_f32, int H, int W, const double Q[16],
+                         int handle_missing, void *d_xyz_f32);
+int sgm_valid_mask_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f32, int64_t n,
+                          void *d_mask_u8);
+/* cell c13 in one call: disparity (int16) -> float disparity -> XYZ; any output may be NULL */
+int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W,
+                        int64_t stride_bytes, const double Q[16], void *d_disp_i16,
+                        void *d_disp_f32, void *d_xyz_f32);
+int sgm_synchronize(sgm_engine *e);
+
+/* per-stage HIP-event timing of the last compute (requires SGM_OPT_PROFILE = 1) */
+int sgm_get_stage_times(sgm_engine *e, sgm_stage_times *out);
+/* algorithmic HBM bytes of one compute at this shape (SURVEY.md 8d model, stated in DESIGN.md) */
+int64_t sgm_algorithmic_bytes(const sgm_params *params, int H, int W, int with_reproject);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -565,7 +565,9 @@ void oracle_reproject_f32(const float *disp, int H, int W, const double Q[16], i
             float *o = xyz + ((int64_t)y * W + x) * 3;
             const double ia = 1.0 / h[3];
             for (int i = 0; i < 3; i++) {
-                float f = (float)h[i];
+                /* volatile: gcc -O3 otherwise folds the float round trip away when it
+                 * vectorises this loop (observed: last-bit differences vs -O0/-O2) */
+                volatile float f = (float)h[i];
                 o[i] = (float)((double)f * ia);
             }
             if (fabs(d - minDisparity) <= FLT_EPSILON) o[2] = 10000.f;

@@ -1,0 +1,91 @@
+"""ctypes binding of include/sgm_hip.h (the C ABI of the HIP library).
+
+The product path has no CPU fallback: if the shared library is missing, or there is no GPU,
+every compute entry point raises.  Nothing in this package imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsgm_hip.so")
+
+SGM_OK = 0
+SGM_TAP_COST, SGM_TAP_AGGR, SGM_TAP_DISP_RAW, SGM_TAP_DISP_MEDIAN = 0, 1, 2, 3
+SGM_OPT_KEEP_AGGR, SGM_OPT_PROFILE = 0, 1
+SGM_MAX_STAGES = 32
+
+# every symbol include/sgm_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "sgm_abi_version", "sgm_device_count", "sgm_last_error", "sgm_create", "sgm_destroy",
+    "sgm_set_option", "sgm_geometry", "sgm_compute", "sgm_compute_batch", "sgm_disp_to_float",
+    "sgm_reproject", "sgm_valid_mask", "sgm_get_tap", "sgm_compute_device",
+    "sgm_disp_to_float_device", "sgm_reproject_device", "sgm_valid_mask_device",
+    "sgm_pipeline_device", "sgm_synchronize", "sgm_get_stage_times", "sgm_algorithmic_bytes",
+)
+
+
+class SgmParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff",
+        "preFilterCap", "uniquenessRatio", "speckleWindowSize", "speckleRange", "mode")]
+
+
+class SgmStageTimes(C.Structure):
+    _fields_ = [("n", C.c_int32), ("name", C.c_char_p * SGM_MAX_STAGES),
+                ("ms", C.c_float * SGM_MAX_STAGES), ("launches", C.c_int32 * SGM_MAX_STAGES)]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libsgm_hip.so; raises LibraryMissing with build instructions when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C stereo_reconstruction_cv_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    pp = C.POINTER(SgmParams)
+    L.sgm_abi_version.restype = i32
+    L.sgm_device_count.restype = i32
+    L.sgm_last_error.restype = C.c_char_p
+    L.sgm_create.argtypes = [pp, i32, vp, C.POINTER(vp)]
+    L.sgm_destroy.argtypes = [vp]
+    L.sgm_destroy.restype = None
+    L.sgm_set_option.argtypes = [vp, i32, i32]
+    L.sgm_geometry.argtypes = [pp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.sgm_compute.argtypes = [vp, vp, vp, i32, i32, i64, vp]
+    L.sgm_compute_batch.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.sgm_disp_to_float.argtypes = [vp, vp, i64, vp]
+    L.sgm_reproject.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    L.sgm_valid_mask.argtypes = [vp, vp, vp, i64, vp]
+    L.sgm_get_tap.argtypes = [vp, i32, vp, i64]
+    L.sgm_compute_device.argtypes = [vp, vp, vp, i32, i32, i64, vp]
+    L.sgm_disp_to_float_device.argtypes = [vp, vp, i64, vp]
+    L.sgm_reproject_device.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    L.sgm_valid_mask_device.argtypes = [vp, vp, vp, i64, vp]
+    L.sgm_pipeline_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, vp, vp]
+    L.sgm_synchronize.argtypes = [vp]
+    L.sgm_get_stage_times.argtypes = [vp, C.POINTER(SgmStageTimes)]
+    L.sgm_algorithmic_bytes.argtypes = [pp, i32, i32, i32]
+    L.sgm_algorithmic_bytes.restype = i64
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("sgm_abi_version", "sgm_device_count"):
+            fn.restype = i32
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return (load().sgm_last_error() or b"").decode("utf-8", "replace")

@@ -1,0 +1,235 @@
+// kernels_cost.h -- matching-cost stage: prefilter + Birchfield-Tomasi pixel cost + box sum.
+//
+// Replaces upstream calcPixelCostBT / hsumBuf / C update inside cv2.StereoSGBM.compute
+// (/root/reference/main.ipynb:668; arithmetic restated in SURVEY.md A.2-A.4 and
+// oracle/sgbm_oracle.c: row_features, bt_row, hsum_row, the C update in sgbm_core).
+//
+//   k_features : u8 image -> per-pixel (value, interval lo, interval hi) for the gradient
+//                and raw channels.  Left image: one packed 8-byte record per pixel (read
+//                wave-uniformly).  Right image: six byte planes stored MIRRORED in x so that
+//                ascending disparity is ascending address.
+//   k_hsum     : one wave per (row, column chunk); lanes span the disparities, the wave walks
+//                x keeping a sliding window of right-image features in registers and a ring of
+//                the last blockSize+1 pixel-cost vectors in LDS -> horizontal running box sum.
+//   k_vsum     : vertical running box sum of hsum rows -> block cost C (no +P2 bias).
+#pragma once
+#include "sgm_device.h"
+
+namespace sgm {
+
+struct Geom {
+    int H, W;
+    int minD, D;
+    int minX1, W1;
+    int SW2, SH2;
+    int P1, P2;
+    int uniq, d12;
+    int ftzero;
+    int invalid_scaled;
+    int mode;
+    int NP;       // packed pairs per lane
+    int64_t rowsz;  // W1 * D
+};
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_features(const uint8_t *__restrict__ img, int64_t stride,
+                                                  int H, int W, int ftzero,
+                                                  uint2 *__restrict__ left_rec,
+                                                  uint8_t *__restrict__ right_planes)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t *row = img + (int64_t)y * stride;
+    const uint8_t *up = y > 0 ? row - stride : row;
+    const uint8_t *dn = y < H - 1 ? row + stride : row;
+
+    int pf[3], rw[3];  // values at x-1, x, x+1 (only read where they exist)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int xx = x + k - 1;
+        if (xx <= 0 || xx >= W - 1) {  // border columns hold ftzero in BOTH channels (A.2)
+            pf[k] = ftzero;
+            rw[k] = ftzero;
+        } else {
+            int g = 2 * ((int)row[xx + 1] - (int)row[xx - 1]) + ((int)up[xx + 1] - (int)up[xx - 1]) +
+                    ((int)dn[xx + 1] - (int)dn[xx - 1]);
+            pf[k] = min(max(g, -ftzero), ftzero) + ftzero;
+            rw[k] = row[xx];
+        }
+    }
+    uint32_t out[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int *v = c == 0 ? pf : rw;
+        const int a = v[1];
+        const int l = x > 0 ? (a + v[0]) / 2 : a;
+        const int r = x < W - 1 ? (a + v[2]) / 2 : a;
+        const int lo = min(a, min(l, r)), hi = max(a, max(l, r));
+        out[c] = (uint32_t)a | ((uint32_t)lo << 8) | ((uint32_t)hi << 16);
+    }
+    if (left_rec) left_rec[(int64_t)y * W + x] = make_uint2(out[0], out[1]);
+    if (right_planes) {
+        const int64_t psz = (int64_t)H * W;
+        const int64_t o = (int64_t)y * W + (W - 1 - x);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            right_planes[(c * 3 + 0) * psz + o] = (uint8_t)(out[c] & 0xff);
+            right_planes[(c * 3 + 1) * psz + o] = (uint8_t)((out[c] >> 8) & 0xff);
+            right_planes[(c * 3 + 2) * psz + o] = (uint8_t)((out[c] >> 16) & 0xff);
+        }
+    }
+}
+
+// Birchfield-Tomasi on packed pairs: min( dist(u, [v0,v1]), dist(v, [u0,u1]) )   (A.3)
+__device__ __forceinline__ uint32_t bt_pair(uint32_t U, uint32_t U0, uint32_t U1, uint32_t V,
+                                            uint32_t V0, uint32_t V1)
+{
+    uint32_t c0 = pk_max_u(pk_subs_u(U, V1), pk_subs_u(V0, U));
+    uint32_t c1 = pk_max_u(pk_subs_u(V, U1), pk_subs_u(U0, V));
+    return pk_min_u(c0, c1);
+}
+
+// LDS layout of one k_hsum workgroup (one wave): [ring RS*64*NP dwords][left records][6 planes]
+struct HsumLds {
+    int ring_bytes, lrec_bytes, seg_len, total_bytes;
+};
+static inline HsumLds hsum_lds_layout(int NP, int RS, int XL, int SW2)
+{
+    HsumLds l;
+    l.ring_bytes = RS * 64 * NP * 4;
+    int nj = XL + 2 * SW2 + 2;
+    l.lrec_bytes = ((nj * 8) + 15) & ~15;
+    l.seg_len = (nj + 128 * NP + 15) & ~15;
+    l.total_bytes = l.ring_bytes + l.lrec_bytes + 6 * l.seg_len;
+    return l;
+}
+
+template <int NP>
+__global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ lrec,
+                                             const uint8_t *__restrict__ rplanes,
+                                             int16_t *__restrict__ hsum, int XL, int nchunks, int RS,
+                                             int ring_bytes, int lrec_bytes, int seg_len)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *ring = reinterpret_cast<uint32_t *>(smem);
+    uint2 *lds_lrec = reinterpret_cast<uint2 *>(smem + ring_bytes);
+    uint8_t *seg = smem + ring_bytes + lrec_bytes;
+
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int y = unit / nchunks, ck = unit - y * nchunks;
+    const int W1 = g.W1, SW2 = g.SW2, W = g.W;
+    const int xs = ck * XL, xe = min(xs + XL, W1);
+    const int j0 = max(xs - SW2 - 1, 0), j1 = min(xe - 1 + SW2, W1 - 1);
+    const int nj = j1 - j0 + 1;
+    const bool active = 2 * NP * lane < g.D;
+
+    // ---- stage this row's features for the chunk ----
+    for (int k = lane; k < nj; k += 64) lds_lrec[k] = lrec[(int64_t)y * W + (j0 + k + g.minX1)];
+    {
+        // mirrored position of (column j, disparity index e): (W-1-(j+minX1)) + minD + e
+        const int base_j1 = W - 1 - (j1 + g.minX1) + g.minD;
+        const int len = (j1 - j0) + 128 * NP;
+        const int64_t psz = (int64_t)g.H * W;
+        for (int s = lane; s < len; s += 64) {
+            const int pos = base_j1 + s;
+            const bool ok = pos >= 0 && pos < W;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                seg[c * seg_len + s] = ok ? rplanes[c * psz + (int64_t)y * W + pos] : (uint8_t)0;
+        }
+    }
+    __syncthreads();  // single wave; orders the LDS staging before the reads below
+
+    // ---- sliding windows of the six right-image planes ----
+    uint32_t w[6][NP];
+    {
+        const int off = (j1 - j0) + 2 * NP * lane;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                w[c][i] = (uint32_t)seg[c * seg_len + off + 2 * i] | ((uint32_t)seg[c * seg_len + off + 2 * i + 1] << 16);
+    }
+
+    uint32_t hs[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) hs[i] = 0;
+    int next_x = xs;
+    int16_t *out_row = hsum + (int64_t)y * g.rowsz + 2 * NP * lane;
+
+    for (int j = j0; j <= j1; j++) {
+        if (j > j0) {
+            const int off = (j1 - j) + 2 * NP * lane;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const uint32_t nw = seg[c * seg_len + off];
+#pragma unroll
+                for (int i = NP - 1; i >= 1; i--) w[c][i] = __builtin_amdgcn_alignbit(w[c][i], w[c][i - 1], 16);
+                w[c][0] = (w[c][0] << 16) | nw;
+            }
+        }
+        const uint2 rec = lds_lrec[j - j0];
+        const uint32_t U = splat16(rec.x & 0xff), U0 = splat16((rec.x >> 8) & 0xff), U1 = splat16((rec.x >> 16) & 0xff);
+        const uint32_t R = splat16(rec.y & 0xff), R0 = splat16((rec.y >> 8) & 0xff), R1 = splat16((rec.y >> 16) & 0xff);
+        uint32_t *slot = ring + ((j % RS) * 64 + lane) * NP;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            uint32_t a = bt_pair(U, U0, U1, w[0][i], w[1][i], w[2][i]);
+            uint32_t b = bt_pair(R, R0, R1, w[3][i], w[4][i], w[5][i]);
+            slot[i] = pk_add(a, pk_shr_u(b, 2));
+        }
+        // every output column whose right-most (clamped) tap is now available
+        while (next_x < xe && min(next_x + SW2, W1 - 1) <= j) {
+            const int x = next_x;
+            if (x == xs) {
+#pragma unroll
+                for (int i = 0; i < NP; i++) hs[i] = 0;
+                for (int t = -SW2; t <= SW2; t++) {
+                    const int jc = min(max(x + t, 0), W1 - 1);
+                    const uint32_t *p = ring + ((jc % RS) * 64 + lane) * NP;
+#pragma unroll
+                    for (int i = 0; i < NP; i++) hs[i] = pk_add(hs[i], p[i]);
+                }
+            } else {
+                const uint32_t *pa = ring + ((min(x + SW2, W1 - 1) % RS) * 64 + lane) * NP;
+                const uint32_t *pb = ring + ((max(x - SW2 - 1, 0) % RS) * 64 + lane) * NP;
+#pragma unroll
+                for (int i = 0; i < NP; i++) hs[i] = pk_sub(pk_add(hs[i], pa[i]), pb[i]);
+            }
+            if (active) {
+                Pack<NP> o;
+#pragma unroll
+                for (int i = 0; i < NP; i++) o.r[i] = hs[i];
+                o.store(out_row + (int64_t)x * g.D);
+            }
+            next_x++;
+        }
+    }
+}
+
+// C(y) = sum_{j=-SH2..SH2} hsum(clamp(y+j, 0, H-1)), running along y inside a band of rows.
+__global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
+                                              int H, int64_t rowsz, int SH2, int RB)
+{
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;  // 8 int16 per thread
+    if (e >= rowsz) return;
+    const int y0 = blockIdx.y * RB, y1 = min(y0 + RB, H);
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int j = -SH2; j <= SH2; j++) {
+        const int yy = min(max(y0 + j, 0), H - 1);
+        const uint4 v = *reinterpret_cast<const uint4 *>(hs + (int64_t)yy * rowsz + e);
+        acc.x = pk_add(acc.x, v.x); acc.y = pk_add(acc.y, v.y); acc.z = pk_add(acc.z, v.z); acc.w = pk_add(acc.w, v.w);
+    }
+    *reinterpret_cast<uint4 *>(C + (int64_t)y0 * rowsz + e) = acc;
+    for (int y = y0 + 1; y < y1; y++) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(hs + (int64_t)min(y + SH2, H - 1) * rowsz + e);
+        const uint4 b = *reinterpret_cast<const uint4 *>(hs + (int64_t)max(y - SH2 - 1, 0) * rowsz + e);
+        acc.x = pk_sub(pk_add(acc.x, a.x), b.x); acc.y = pk_sub(pk_add(acc.y, a.y), b.y);
+        acc.z = pk_sub(pk_add(acc.z, a.z), b.z); acc.w = pk_sub(pk_add(acc.w, a.w), b.w);
+        *reinterpret_cast<uint4 *>(C + (int64_t)y * rowsz + e) = acc;
+    }
+}
+
+}  // namespace sgm

@@ -1,0 +1,267 @@
+// kernels_post.h -- everything after the aggregated cost: right-view map + sub-pixel + LR check,
+// 3x3 median, speckle filter (parallel connected components), float scaling/masking,
+// reprojection to XYZ and the validity mask.
+//
+// Replaces, in order: the tail of upstream computeDisparitySGBM, medianBlur(disp, disp, 3) and
+// filterSpeckles inside stereo.compute (/root/reference/main.ipynb:668),
+// the numpy lines main.ipynb:668-670, cv2.reprojectImageTo3D (main.ipynb:697; SURVEY.md
+// Appendix B) and the mask of main.ipynb:726-730.  CPU restatement: oracle/sgbm_oracle.c.
+#pragma once
+#include "kernels_cost.h"
+#include <float.h>
+
+namespace sgm {
+
+// ------------------------------------------------------------------------------------------
+// One workgroup per image row.  The right-view disparity map of upstream ("disp2", filled in
+// descending x, a candidate replaces the holder only with a strictly smaller cost) is the
+// argmin over candidates of (cost, then larger x): an LDS atomicMin on (cost << 16 | 0xffff-x).
+__global__ __launch_bounds__(256) void k_select(Geom g, const uint2 *__restrict__ wta,
+                                                int16_t *__restrict__ disp)
+{
+    extern __shared__ uint32_t keys[];  // W entries
+    const int y = blockIdx.x, W = g.W, maxX1 = g.minX1 + g.W1;
+    const int INV = g.invalid_scaled;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) keys[x] = 0xffffffffu;
+    __syncthreads();
+    for (int x = g.minX1 + threadIdx.x; x < maxX1; x += blockDim.x) {
+        const uint32_t k = wta[(int64_t)y * W + x].x;
+        if (k != 0xffffffffu) {
+            const int best = (int)(k & 0xffffu);
+            const int x2 = x - best - g.minD;
+            atomicMin(&keys[x2], (k & 0xffff0000u) | (uint32_t)(0xffff - x));
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        int d1 = INV;
+        if (x >= g.minX1 && x < maxX1) {
+            const uint2 kv = wta[(int64_t)y * W + x];
+            if (kv.x != 0xffffffffu) {
+                const int best = (int)(kv.x & 0xffffu), s0 = (int)(kv.x >> 16);
+                int dsc = best * 16;
+                if (best > 0 && best < g.D - 1) {
+                    const int sm = (int)(kv.y & 0xffffu), sp = (int)(kv.y >> 16);
+                    const int denom2 = max(sm + sp - 2 * s0, 1);
+                    dsc += ((sm - sp) * 16 + denom2) / (denom2 * 2);  // C division, toward zero
+                }
+                d1 = dsc + g.minD * 16;
+            }
+        }
+        if (d1 != INV) {
+            const int lo = d1 >> 4, hi = (d1 + 15) >> 4;
+            const int xa = x - lo, xb = x - hi;
+            bool kill = false;
+            if (xa >= 0 && xa < W && xb >= 0 && xb < W) {
+                const uint32_t ka = keys[xa], kb = keys[xb];
+                const int da = ka == 0xffffffffu ? INV : (0xffff - (int)(ka & 0xffffu)) - xa;
+                const int db = kb == 0xffffffffu ? INV : (0xffff - (int)(kb & 0xffffu)) - xb;
+                kill = da >= g.minD && abs(da - lo) > g.d12 && db >= g.minD && abs(db - hi) > g.d12;
+            }
+            if (kill) d1 = INV;
+        }
+        disp[(int64_t)y * W + x] = (int16_t)d1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(int &a, int &b)
+{
+    const int lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+
+__global__ __launch_bounds__(256) void k_median3(const int16_t *__restrict__ src,
+                                                 int16_t *__restrict__ dst, int H, int W)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int16_t *r0 = src + (int64_t)max(y - 1, 0) * W;
+    const int16_t *r1 = src + (int64_t)y * W;
+    const int16_t *r2 = src + (int64_t)min(y + 1, H - 1) * W;
+    const int xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+    int p0 = r0[xl], p1 = r0[x], p2 = r0[xr], p3 = r1[xl], p4 = r1[x], p5 = r1[xr], p6 = r2[xl], p7 = r2[x], p8 = r2[xr];
+    // 19-exchange median-of-9 network
+    cswap(p1, p2); cswap(p4, p5); cswap(p7, p8); cswap(p0, p1); cswap(p3, p4); cswap(p6, p7);
+    cswap(p1, p2); cswap(p4, p5); cswap(p7, p8); cswap(p0, p3); cswap(p5, p8); cswap(p4, p7);
+    cswap(p3, p6); cswap(p1, p4); cswap(p2, p5); cswap(p4, p7); cswap(p4, p2); cswap(p6, p4);
+    cswap(p4, p2);
+    dst[(int64_t)y * W + x] = (int16_t)p4;
+}
+
+// ------------------------------------------------------------------------------------------
+// Speckle filter as lock-free union-find over the 4-neighbour graph (A.8): the component
+// partition, hence the output, does not depend on the traversal order upstream uses.
+// Parent links only ever decrease (atomicMin), so a stale value is still an ancestor; the loads
+// are agent-scope (L2) all the same: a CU's L1 is never refreshed by other CUs' atomics.
+__device__ __forceinline__ int uf_load(const int *L, int a)
+{
+    return __hip_atomic_load(L + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(const int *L, int a)
+{
+    int p = uf_load(L, a);
+    while (p != a) {
+        a = p;
+        p = uf_load(L, a);
+    }
+    return a;
+}
+
+__device__ __forceinline__ void uf_union(int *L, int a, int b)
+{
+    bool done;
+    do {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a < b) {
+            const int old = atomicMin(&L[b], a);
+            done = (old == b);
+            b = old;
+        } else if (b < a) {
+            const int old = atomicMin(&L[a], b);
+            done = (old == a);
+            a = old;
+        } else {
+            done = true;
+        }
+    } while (!done);
+}
+
+__global__ __launch_bounds__(256) void k_ccl_init(const int16_t *__restrict__ img, int *__restrict__ label,
+                                                  int *__restrict__ size, int64_t n, int newVal)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    label[i] = img[i] != newVal ? (int)i : -1;
+    size[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_merge(const int16_t *__restrict__ img, int *label, int H, int W,
+                                                   int newVal, int maxDiff)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int64_t i = (int64_t)y * W + x;
+    const int v = img[i];
+    if (v == newVal) return;
+    if (x > 0) {
+        const int u = img[i - 1];
+        if (u != newVal && abs(v - u) <= maxDiff) uf_union(label, (int)i, (int)(i - 1));
+    }
+    if (y > 0) {
+        const int u = img[i - W];
+        if (u != newVal && abs(v - u) <= maxDiff) uf_union(label, (int)i, (int)(i - W));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_count(int *label, int *__restrict__ size, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (label[i] < 0) return;
+    const int r = uf_find(label, (int)i);
+    label[i] = r;  // any concurrent reader still sees an ancestor of its root
+    atomicAdd(&size[r], 1);
+}
+
+__global__ __launch_bounds__(256) void k_ccl_apply(int16_t *__restrict__ img, const int *__restrict__ label,
+                                                   const int *__restrict__ size, int64_t n, int newVal,
+                                                   int maxSpeckleSize)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = label[i];
+    if (r < 0) return;
+    // label[i] is i's root or (if written before a later flatten) an ancestor; roots are fixed
+    // points, so walk to be safe
+    int a = r, p = label[a];
+    while (p != a) {
+        a = p;
+        p = label[a];
+    }
+    if (size[a] <= maxSpeckleSize) img[i] = (int16_t)newVal;
+}
+
+// ------------------------------------------------------------------------------------------
+// main.ipynb:668-670 : f = i16 / 16 ; f * float(f > 0)   (invalid -> -0.0, zero -> +0.0)
+__global__ __launch_bounds__(256) void k_disp_to_float(const int16_t *__restrict__ d, float *__restrict__ out,
+                                                       int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float f = (float)d[i] / 16.0f;
+    out[i] = f * (f > 0.0f ? 1.0f : 0.0f);
+}
+
+// order-preserving float <-> uint key for atomicMin
+__device__ __forceinline__ uint32_t fkey(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void k_min_f32(const float *__restrict__ d, int64_t n, uint32_t *minkey)
+{
+    uint32_t k = 0xffffffffu;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        k = min(k, fkey(d[i]));
+    k = wave_min_u32(k);
+    if ((threadIdx.x & 63) == 0) atomicMin(minkey, k);
+}
+
+struct QMat {
+    double q[16];
+};
+
+// Appendix B: homogeneous point in double, sums in index order from 0, one rounding to float,
+// divide as multiply by the reciprocal, one more rounding.  The library is built with
+// -ffp-contract=off so that no fused multiply-add changes the double arithmetic.
+__global__ __launch_bounds__(256) void k_reproject(const float *__restrict__ disp, int H, int W, QMat Q,
+                                                   const uint32_t *minkey, float *__restrict__ xyz)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int64_t i = (int64_t)y * W + x;
+    const double d = (double)disp[i];
+    const double v[4] = {(double)x, (double)y, d, 1.0};
+    double h[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s += Q.q[r * 4 + k] * v[k];
+        h[r] = s;
+    }
+    const double ia = 1.0 / h[3];
+    float o[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float f = (float)h[r];
+        o[r] = (float)((double)f * ia);
+    }
+    if (minkey) {
+        const double mn = (double)fkey_inv(*minkey);
+        if (fabs(d - mn) <= (double)FLT_EPSILON) o[2] = 10000.f;
+    }
+    xyz[i * 3 + 0] = o[0];
+    xyz[i * 3 + 1] = o[1];
+    xyz[i * 3 + 2] = o[2];
+}
+
+// main.ipynb:726-730
+__global__ __launch_bounds__(256) void k_valid_mask(const float *__restrict__ xyz, const float *__restrict__ disp,
+                                                    int64_t n, uint8_t *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float X = xyz[i * 3];
+    mask[i] = (uint8_t)(!isnan(X) && !isinf(X) && disp[i] > 0.0f);
+}
+
+}  // namespace sgm

@@ -1,0 +1,95 @@
+// sgm_device.h -- wave64 / packed-int16 building blocks for gfx950 (CDNA4).
+//
+// Layout convention used by every cost-volume kernel: a volume is int16 [y][xi][d] with d
+// fastest.  One wavefront owns one pixel's D disparities: lane l holds NP packed pairs
+// (32-bit registers of two int16), pair i of lane l = disparities d = 2*(NP*l + i) + {0,1}.
+// NP = 1, 2, 4 covers D <= 128, 256, 512; lanes whose first disparity is >= D are idle
+// ("partial" waves, D % 16 == 0 makes a lane either fully valid or fully idle).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sgm {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t bits(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t bits(v2u v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ v2s as_s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ v2u as_u(uint32_t v) { return __builtin_bit_cast(v2u, v); }
+__device__ __forceinline__ uint32_t splat16(uint32_t v) { return (v & 0xffffu) | (v << 16); }
+
+// packed int16 arithmetic on raw 32-bit registers
+__device__ __forceinline__ uint32_t pk_min_s(uint32_t a, uint32_t b) { return bits(__builtin_elementwise_min(as_s(a), as_s(b))); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return bits(as_u(a) + as_u(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return bits(as_u(a) - as_u(b)); }
+__device__ __forceinline__ uint32_t pk_adds_s(uint32_t a, uint32_t b) { return bits(__builtin_elementwise_add_sat(as_s(a), as_s(b))); }  // v_pk_add_i16 clamp
+__device__ __forceinline__ uint32_t pk_subs_u(uint32_t a, uint32_t b) { return bits(__builtin_elementwise_sub_sat(as_u(a), as_u(b))); }  // max(0, a-b)
+__device__ __forceinline__ uint32_t pk_max_u(uint32_t a, uint32_t b) { return bits(__builtin_elementwise_max(as_u(a), as_u(b))); }
+__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) { return bits(__builtin_elementwise_min(as_u(a), as_u(b))); }
+__device__ __forceinline__ uint32_t pk_shr_u(uint32_t a, int s) { return bits(as_u(a) >> (unsigned short)s); }
+
+// DPP controls (GFX9 encodings)
+enum : int {
+    DPP_QUAD_1032 = 0xB1,
+    DPP_QUAD_2301 = 0x4E,
+    DPP_ROW_HALF_MIRROR = 0x141,
+    DPP_ROW_MIRROR = 0x140,
+    DPP_WAVE_SHL1 = 0x130,  // lane i reads lane i+1
+    DPP_WAVE_SHR1 = 0x138,  // lane i reads lane i-1
+};
+
+// lane i <- lane i-1 ; lane 0 <- fill
+__device__ __forceinline__ uint32_t from_lower_lane(uint32_t v, uint32_t fill)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+// lane i <- lane i+1 ; lane 63 <- fill
+__device__ __forceinline__ uint32_t from_upper_lane(uint32_t v, uint32_t fill)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, DPP_WAVE_SHL1, 0xf, 0xf, false);
+}
+
+// min over the 64 lanes of an unsigned 32-bit value; result is wave-uniform (SGPR)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_QUAD_1032, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_QUAD_2301, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_MIRROR, 0xf, 0xf, false));
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+// NP packed registers per lane, moved as one vector access
+template <int NP> struct PackVec;
+template <> struct PackVec<1> { typedef uint32_t type; };
+template <> struct PackVec<2> { typedef uint2 type; };
+template <> struct PackVec<4> { typedef uint4 type; };
+
+template <int NP> struct Pack {
+    uint32_t r[NP];
+    __device__ __forceinline__ void load(const int16_t *p)
+    {
+        typename PackVec<NP>::type v = *reinterpret_cast<const typename PackVec<NP>::type *>(p);
+        __builtin_memcpy(r, &v, sizeof(v));
+    }
+    __device__ __forceinline__ void store(int16_t *p) const
+    {
+        typename PackVec<NP>::type v;
+        __builtin_memcpy(&v, r, sizeof(v));
+        *reinterpret_cast<typename PackVec<NP>::type *>(p) = v;
+    }
+    __device__ __forceinline__ void fill(uint32_t x)
+    {
+#pragma unroll
+        for (int i = 0; i < NP; i++) r[i] = x;
+    }
+};
+
+#define SGM_MAX_COST 32767
+#define SGM_SENT 0x7fff7fffu  // packed pair of MAX_COST
+
+}  // namespace sgm

@@ -1,0 +1,681 @@
+// sgm_engine.hip -- host side of the C ABI declared in include/sgm_hip.h.
+//
+// Owns the device buffers and the stage schedule of one stereo matcher on one GPU / stream.
+// Mirrors the reference's call shape (cv2.StereoSGBM_create -> .compute -> reprojectImageTo3D,
+// /root/reference/main.ipynb:655-670, 697); see the header for the per-entry-point mapping.
+#include "../../include/sgm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels_cost.h"
+#include "kernels_path.h"
+#include "kernels_post.h"
+
+using namespace sgm;
+
+// ---- error plumbing ----------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return set_err(SGM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                           __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// ---- engine --------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SGM_OK;
+        if (p) {
+            if (hipFree(p) != hipSuccess) return SGM_ERR_HIP;
+            p = nullptr;
+            cap = 0;
+        }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            set_err(SGM_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return SGM_ERR_NOMEM;
+        }
+        cap = bytes;
+        return SGM_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct sgm_engine {
+    sgm_params params;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int keep_aggr = 0;
+    int profile = 0;
+
+    // shape of the last compute
+    int H = 0, W = 0;
+    Geom g{};
+
+    DevBuf in_left, in_right;           // staging for host-pointer calls
+    DevBuf lrec, rplanes;               // features
+    DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
+    DevBuf wta;                         // uint2 [H][W]
+    DevBuf disp_raw, disp_med, disp_out;  // int16 [H][W]
+    DevBuf label, csize;                // int32 [H][W] each
+    DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
+
+    // profiling
+    std::vector<hipEvent_t> events;
+    std::vector<const char *> stage_names;
+    std::vector<int> stage_launches;
+    int nstages = 0;
+};
+
+static int normalise(const sgm_params *p, int H, int W, Geom *g)
+{
+    if (p->numDisparities <= 0) return set_err(SGM_ERR_INVALID_ARG, "numDisparities must be > 0");
+    if (p->mode != 0 && p->mode != 1)
+        return set_err(SGM_ERR_UNSUPPORTED, "mode %d: only MODE_SGBM (0) and MODE_HH (1) are built; the reference never selects 3WAY/HH4", p->mode);
+    if (p->numDisparities % 16 != 0)
+        return set_err(SGM_ERR_UNSUPPORTED, "numDisparities=%d must be divisible by 16 (OpenCV's documented contract)", p->numDisparities);
+    if (p->numDisparities > 512) return set_err(SGM_ERR_UNSUPPORTED, "numDisparities=%d > 512", p->numDisparities);
+    const int dim = p->blockSize > 0 ? p->blockSize : 5;
+    if (dim > 31) return set_err(SGM_ERR_UNSUPPORTED, "blockSize=%d > 31", dim);
+    g->H = H;
+    g->W = W;
+    g->minD = p->minDisparity;
+    g->D = p->numDisparities;
+    const int maxD = g->minD + g->D;
+    g->minX1 = std::max(maxD, 0);
+    const int maxX1 = W + std::min(g->minD, 0);
+    g->W1 = maxX1 - g->minX1;
+    g->SW2 = g->SH2 = dim / 2;
+    g->P1 = p->P1 > 0 ? p->P1 : 2;
+    g->P2 = std::max(p->P2 > 0 ? p->P2 : 5, g->P1 + 1);
+    g->uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    g->d12 = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
+    g->ftzero = std::max(p->preFilterCap, 15) | 1;
+    g->invalid_scaled = (g->minD - 1) * 16;
+    g->mode = p->mode;
+    g->NP = g->D <= 128 ? 1 : (g->D <= 256 ? 2 : 4);
+    g->rowsz = (int64_t)std::max(g->W1, 0) * g->D;
+    return SGM_OK;
+}
+
+// ---- stage bookkeeping -----------------------------------------------------------------------
+static int stage_begin(sgm_engine *e, const char *name)
+{
+    if (!e->profile) return SGM_OK;
+    if (e->nstages >= SGM_MAX_STAGES) return SGM_OK;
+    const size_t need = (size_t)(e->nstages + 1) * 2;
+    while (e->events.size() < need) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        e->events.push_back(ev);
+    }
+    e->stage_names.resize(e->nstages + 1);
+    e->stage_launches.resize(e->nstages + 1);
+    e->stage_names[e->nstages] = name;
+    e->stage_launches[e->nstages] = 0;
+    HIP_TRY(hipEventRecord(e->events[e->nstages * 2], e->stream));
+    return SGM_OK;
+}
+static int stage_end(sgm_engine *e, int launches)
+{
+    if (!e->profile) return SGM_OK;
+    if (e->nstages >= SGM_MAX_STAGES) return SGM_OK;
+    e->stage_launches[e->nstages] = launches;
+    HIP_TRY(hipEventRecord(e->events[e->nstages * 2 + 1], e->stream));
+    e->nstages++;
+    return SGM_OK;
+}
+
+#define KCHECK() HIP_TRY(hipGetLastError())
+
+// ---- path launch dispatch ---------------------------------------------------------------------
+template <int NP, bool PARTIAL>
+static void launch_path_np(const Geom &g, int rx, int ry, int mode, const int16_t *C, int16_t *S, int keepS,
+                           uint2 *wta, hipStream_t st)
+{
+    const int nlines = ry == 0 ? g.H : g.W1;
+    dim3 grid(nlines), block(64);
+    if (mode == PATH_FIRST)
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_FIRST>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta);
+    else if (mode == PATH_ACCUM)
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_ACCUM>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta);
+    else
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_LAST>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta);
+}
+
+static void launch_path(const Geom &g, int rx, int ry, int mode, const int16_t *C, int16_t *S, int keepS,
+                        uint2 *wta, hipStream_t st)
+{
+    const bool partial = g.D != 128 * g.NP;
+    if (g.NP == 1) {
+        if (partial) launch_path_np<1, true>(g, rx, ry, mode, C, S, keepS, wta, st);
+        else launch_path_np<1, false>(g, rx, ry, mode, C, S, keepS, wta, st);
+    } else if (g.NP == 2) {
+        if (partial) launch_path_np<2, true>(g, rx, ry, mode, C, S, keepS, wta, st);
+        else launch_path_np<2, false>(g, rx, ry, mode, C, S, keepS, wta, st);
+    } else {
+        if (partial) launch_path_np<4, true>(g, rx, ry, mode, C, S, keepS, wta, st);
+        else launch_path_np<4, false>(g, rx, ry, mode, C, S, keepS, wta, st);
+    }
+}
+
+// ---- the matcher on device buffers ---------------------------------------------------------
+static int ensure_buffers(sgm_engine *e, int H, int W)
+{
+    Geom g;
+    int rc = normalise(&e->params, H, W, &g);
+    if (rc) return rc;
+    e->g = g;
+    e->H = H;
+    e->W = W;
+    const size_t npx = (size_t)H * W;
+    const size_t vol = (size_t)std::max<int64_t>(g.rowsz, 0) * H * sizeof(int16_t);
+    if ((rc = e->lrec.ensure(npx * 8))) return rc;
+    if ((rc = e->rplanes.ensure(npx * 6))) return rc;
+    if (vol) {
+        if ((rc = e->hsum.ensure(vol))) return rc;
+        if ((rc = e->cost.ensure(vol))) return rc;
+        if ((rc = e->aggr.ensure(vol))) return rc;
+    }
+    if ((rc = e->wta.ensure(npx * 8))) return rc;
+    if ((rc = e->disp_raw.ensure(npx * 2))) return rc;
+    if ((rc = e->disp_med.ensure(npx * 2))) return rc;
+    if ((rc = e->label.ensure(npx * 4))) return rc;
+    if ((rc = e->csize.ensure(npx * 4))) return rc;
+    return SGM_OK;
+}
+
+__global__ void k_fill_i16(int16_t *p, int64_t n, int16_t v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_right, int H, int W,
+                       int64_t stride, int16_t *d_disp)
+{
+    if (!e || !d_left || !d_right || !d_disp) return set_err(SGM_ERR_INVALID_ARG, "null pointer");
+    if (H <= 0 || W < 2 || stride < W) return set_err(SGM_ERR_INVALID_ARG, "bad shape H=%d W=%d stride=%lld", H, W, (long long)stride);
+    if (W > 32767 || H > 32767) return set_err(SGM_ERR_UNSUPPORTED, "image larger than 32767 in a dimension");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = ensure_buffers(e, H, W);
+    if (rc) return rc;
+    const Geom &g = e->g;
+    hipStream_t st = e->stream;
+    e->nstages = 0;
+    const int64_t npx = (int64_t)H * W;
+    const unsigned nb_px = (unsigned)((npx + 255) / 256);
+
+    int16_t *raw = (int16_t *)e->disp_raw.p, *med = (int16_t *)e->disp_med.p;
+
+    if (g.W1 <= 0) {
+        // no column can be matched: the whole map is invalid (upstream early-out), then median
+        // and speckle act on a constant image
+        if ((rc = stage_begin(e, "fill_invalid"))) return rc;
+        hipLaunchKernelGGL(k_fill_i16, dim3(nb_px), dim3(256), 0, st, raw, npx, (int16_t)g.invalid_scaled);
+        KCHECK();
+        if ((rc = stage_end(e, 1))) return rc;
+    } else {
+        const int16_t *C = (const int16_t *)e->cost.p;
+        int16_t *S = (int16_t *)e->aggr.p;
+        int16_t *HS = (int16_t *)e->hsum.p;
+        uint2 *wta = (uint2 *)e->wta.p;
+
+        // -- features
+        if ((rc = stage_begin(e, "features"))) return rc;
+        {
+            dim3 grid((W + 255) / 256, H), block(256);
+            hipLaunchKernelGGL(k_features, grid, block, 0, st, d_left, stride, H, W, g.ftzero, (uint2 *)e->lrec.p, (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_features, grid, block, 0, st, d_right, stride, H, W, g.ftzero, (uint2 *)nullptr, (uint8_t *)e->rplanes.p);
+            KCHECK();
+        }
+        if ((rc = stage_end(e, 2))) return rc;
+
+        // -- horizontal box sum of the pixel cost
+        if ((rc = stage_begin(e, "cost_hsum"))) return rc;
+        {
+            const int XL = 128;
+            const int nchunks = (g.W1 + XL - 1) / XL;
+            const int RS = 2 * g.SW2 + 2;
+            const HsumLds l = hsum_lds_layout(g.NP, RS, XL, g.SW2);
+            dim3 grid((unsigned)((int64_t)H * nchunks)), block(64);
+            const uint2 *lrec = (const uint2 *)e->lrec.p;
+            const uint8_t *rpl = (const uint8_t *)e->rplanes.p;
+            if (g.NP == 1) {
+                if (l.total_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_hsum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, l.total_bytes));
+                hipLaunchKernelGGL(k_hsum<1>, grid, block, l.total_bytes, st, g, lrec, rpl, HS, XL, nchunks, RS, l.ring_bytes, l.lrec_bytes, l.seg_len);
+            } else if (g.NP == 2) {
+                if (l.total_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_hsum<2>, hipFuncAttributeMaxDynamicSharedMemorySize, l.total_bytes));
+                hipLaunchKernelGGL(k_hsum<2>, grid, block, l.total_bytes, st, g, lrec, rpl, HS, XL, nchunks, RS, l.ring_bytes, l.lrec_bytes, l.seg_len);
+            } else {
+                if (l.total_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_hsum<4>, hipFuncAttributeMaxDynamicSharedMemorySize, l.total_bytes));
+                hipLaunchKernelGGL(k_hsum<4>, grid, block, l.total_bytes, st, g, lrec, rpl, HS, XL, nchunks, RS, l.ring_bytes, l.lrec_bytes, l.seg_len);
+            }
+            KCHECK();
+        }
+        if ((rc = stage_end(e, 1))) return rc;
+
+        // -- vertical box sum -> block cost
+        if ((rc = stage_begin(e, "cost_vsum"))) return rc;
+        {
+            const int RB = 64;
+            dim3 grid((unsigned)((g.rowsz / 8 + 255) / 256), (H + RB - 1) / RB), block(256);
+            hipLaunchKernelGGL(k_vsum, grid, block, 0, st, (const int16_t *)HS, (int16_t *)e->cost.p, H, g.rowsz, g.SH2, RB);
+            KCHECK();
+        }
+        if ((rc = stage_end(e, 1))) return rc;
+
+        // -- path aggregation: vertical-ish first, horizontal last (the last one does WTA)
+        struct Dir { int rx, ry; const char *name; };
+        static const Dir down[3] = {{0, 1, "path_S"}, {1, 1, "path_SE"}, {-1, 1, "path_SW"}};
+        static const Dir upw[3] = {{0, -1, "path_N"}, {1, -1, "path_NE"}, {-1, -1, "path_NW"}};
+        bool first = true;
+        for (int k = 0; k < 3; k++) {
+            if ((rc = stage_begin(e, down[k].name))) return rc;
+            launch_path(g, down[k].rx, down[k].ry, first ? PATH_FIRST : PATH_ACCUM, C, S, 0, wta, st);
+            KCHECK();
+            first = false;
+            if ((rc = stage_end(e, 1))) return rc;
+        }
+        if (g.mode == 1) {
+            for (int k = 0; k < 3; k++) {
+                if ((rc = stage_begin(e, upw[k].name))) return rc;
+                launch_path(g, upw[k].rx, upw[k].ry, PATH_ACCUM, C, S, 0, wta, st);
+                KCHECK();
+                if ((rc = stage_end(e, 1))) return rc;
+            }
+        }
+        if ((rc = stage_begin(e, "path_E"))) return rc;
+        launch_path(g, 1, 0, PATH_ACCUM, C, S, 0, wta, st);
+        KCHECK();
+        if ((rc = stage_end(e, 1))) return rc;
+        if ((rc = stage_begin(e, "path_W_wta"))) return rc;
+        launch_path(g, -1, 0, PATH_LAST, C, S, e->keep_aggr, wta, st);
+        KCHECK();
+        if ((rc = stage_end(e, 1))) return rc;
+
+        // -- right view, sub-pixel, LR check
+        if ((rc = stage_begin(e, "select_lr"))) return rc;
+        {
+            const size_t lds = (size_t)W * 4;
+            if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_select, dim3(H), dim3(256), lds, st, g, (const uint2 *)wta, raw);
+            KCHECK();
+        }
+        if ((rc = stage_end(e, 1))) return rc;
+    }
+
+    // -- 3x3 median
+    if ((rc = stage_begin(e, "median3"))) return rc;
+    {
+        dim3 grid((W + 255) / 256, H), block(256);
+        hipLaunchKernelGGL(k_median3, grid, block, 0, st, (const int16_t *)raw, med, H, W);
+        KCHECK();
+    }
+    if ((rc = stage_end(e, 1))) return rc;
+
+    // -- speckle filter -> output
+    if ((rc = stage_begin(e, "speckle"))) return rc;
+    int nl = 1;
+    HIP_TRY(hipMemcpyAsync(d_disp, med, (size_t)npx * 2, hipMemcpyDeviceToDevice, st));
+    if (e->params.speckleWindowSize > 0) {
+        const int newVal = (e->params.minDisparity - 1) * 16;
+        const int maxDiff = 16 * e->params.speckleRange;
+        int *label = (int *)e->label.p, *csz = (int *)e->csize.p;
+        dim3 g2((W + 255) / 256, H);
+        hipLaunchKernelGGL(k_ccl_init, dim3(nb_px), dim3(256), 0, st, (const int16_t *)d_disp, label, csz, npx, newVal);
+        hipLaunchKernelGGL(k_ccl_merge, g2, dim3(256), 0, st, (const int16_t *)d_disp, label, H, W, newVal, maxDiff);
+        hipLaunchKernelGGL(k_ccl_count, dim3(nb_px), dim3(256), 0, st, label, csz, npx);
+        hipLaunchKernelGGL(k_ccl_apply, dim3(nb_px), dim3(256), 0, st, d_disp, (const int *)label, (const int *)csz, npx, newVal, e->params.speckleWindowSize);
+        KCHECK();
+        nl = 5;
+    }
+    if ((rc = stage_end(e, nl))) return rc;
+    return SGM_OK;
+}
+
+static int run_to_float(sgm_engine *e, const int16_t *d_disp, int64_t n, float *d_out)
+{
+    hipLaunchKernelGGL(k_disp_to_float, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, d_disp, d_out, n);
+    KCHECK();
+    return SGM_OK;
+}
+
+static int run_reproject(sgm_engine *e, const float *d_disp, int H, int W, const double Q[16], int handle_missing,
+                         float *d_xyz)
+{
+    if (!Q) return set_err(SGM_ERR_INVALID_ARG, "Q is null");
+    QMat q;
+    memcpy(q.q, Q, sizeof(q.q));
+    uint32_t *mk = nullptr;
+    if (handle_missing) {
+        int rc = e->minkey.ensure(4);
+        if (rc) return rc;
+        mk = (uint32_t *)e->minkey.p;
+        HIP_TRY(hipMemsetAsync(mk, 0xff, 4, e->stream));
+        const int64_t n = (int64_t)H * W;
+        const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_min_f32, dim3(nb), dim3(256), 0, e->stream, d_disp, n, mk);
+    }
+    dim3 grid((W + 255) / 256, H), block(256);
+    hipLaunchKernelGGL(k_reproject, grid, block, 0, e->stream, d_disp, H, W, q, (const uint32_t *)mk, d_xyz);
+    KCHECK();
+    return SGM_OK;
+}
+
+// ---- exported C ABI -------------------------------------------------------------------------------
+extern "C" {
+
+int sgm_abi_version(void) { return SGM_ABI_VERSION; }
+
+const char *sgm_last_error(void) { return g_err; }
+
+int sgm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sgm_geometry(const sgm_params *params, int W, int *minX1, int *W1)
+{
+    if (!params) return set_err(SGM_ERR_INVALID_ARG, "params is null");
+    Geom g;
+    int rc = normalise(params, 1, W, &g);
+    if (rc) return rc;
+    if (minX1) *minX1 = g.minX1;
+    if (W1) *W1 = g.W1;
+    return SGM_OK;
+}
+
+int sgm_create(const sgm_params *params, int device_id, void *stream, sgm_engine **out)
+{
+    if (!params || !out) return set_err(SGM_ERR_INVALID_ARG, "params/out is null");
+    *out = nullptr;
+    Geom g;
+    int rc = normalise(params, 1, 64, &g);  // parameter validation only
+    if (rc) return rc;
+    int n = 0;
+    hipError_t he = hipGetDeviceCount(&n);
+    if (he != hipSuccess || n <= 0)
+        return set_err(SGM_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                       he == hipSuccess ? "device count 0" : hipGetErrorString(he));
+    if (device_id < 0 || device_id >= n) return set_err(SGM_ERR_NO_DEVICE, "device_id %d out of range [0,%d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    sgm_engine *e = new (std::nothrow) sgm_engine();
+    if (!e) return set_err(SGM_ERR_NOMEM, "out of host memory");
+    e->params = *params;
+    e->device = device_id;
+    if (stream) {
+        e->stream = (hipStream_t)stream;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete e;
+            return set_err(SGM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se));
+        }
+        e->own_stream = true;
+    }
+    *out = e;
+    return SGM_OK;
+}
+
+void sgm_destroy(sgm_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta,
+                      &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->f32, &e->xyz, &e->mask,
+                      &e->minkey};
+    for (DevBuf *b : bufs) b->release();
+    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int sgm_set_option(sgm_engine *e, int option, int value)
+{
+    if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
+    if (option == SGM_OPT_KEEP_AGGR) e->keep_aggr = value ? 1 : 0;
+    else if (option == SGM_OPT_PROFILE) e->profile = value ? 1 : 0;
+    else return set_err(SGM_ERR_INVALID_ARG, "unknown option %d", option);
+    return SGM_OK;
+}
+
+int sgm_synchronize(sgm_engine *e)
+{
+    if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_compute_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W, int64_t stride_bytes,
+                       void *d_disp_i16)
+{
+    return run_compute(e, (const uint8_t *)d_left, (const uint8_t *)d_right, H, W, stride_bytes, (int16_t *)d_disp_i16);
+}
+
+int sgm_disp_to_float_device(sgm_engine *e, const void *d_disp_i16, int64_t n, void *d_out_f32)
+{
+    if (!e || !d_disp_i16 || !d_out_f32 || n <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return run_to_float(e, (const int16_t *)d_disp_i16, n, (float *)d_out_f32);
+}
+
+int sgm_reproject_device(sgm_engine *e, const void *d_disp_f32, int H, int W, const double Q[16], int handle_missing,
+                         void *d_xyz_f32)
+{
+    if (!e || !d_disp_f32 || !d_xyz_f32 || H <= 0 || W <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return run_reproject(e, (const float *)d_disp_f32, H, W, Q, handle_missing, (float *)d_xyz_f32);
+}
+
+int sgm_valid_mask_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f32, int64_t n, void *d_mask_u8)
+{
+    if (!e || !d_xyz || !d_disp_f32 || !d_mask_u8 || n <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_valid_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const float *)d_xyz,
+                       (const float *)d_disp_f32, n, (uint8_t *)d_mask_u8);
+    KCHECK();
+    return SGM_OK;
+}
+
+int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W, int64_t stride_bytes,
+                        const double Q[16], void *d_disp_i16, void *d_disp_f32, void *d_xyz_f32)
+{
+    if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
+    const int64_t n = (int64_t)H * W;
+    int rc;
+    int16_t *di = (int16_t *)d_disp_i16;
+    if (!di) {
+        if ((rc = e->disp_out.ensure((size_t)n * 2))) return rc;
+        di = (int16_t *)e->disp_out.p;
+    }
+    if ((rc = run_compute(e, (const uint8_t *)d_left, (const uint8_t *)d_right, H, W, stride_bytes, di))) return rc;
+    if (!d_disp_f32 && !d_xyz_f32) return SGM_OK;
+    float *df = (float *)d_disp_f32;
+    if (!df) {
+        if ((rc = e->f32.ensure((size_t)n * 4))) return rc;
+        df = (float *)e->f32.p;
+    }
+    if ((rc = stage_begin(e, "to_float"))) return rc;
+    if ((rc = run_to_float(e, di, n, df))) return rc;
+    if ((rc = stage_end(e, 1))) return rc;
+    if (d_xyz_f32) {
+        if ((rc = stage_begin(e, "reproject"))) return rc;
+        if ((rc = run_reproject(e, df, H, W, Q, 0, (float *)d_xyz_f32))) return rc;
+        if ((rc = stage_end(e, 1))) return rc;
+    }
+    return SGM_OK;
+}
+
+int sgm_compute(sgm_engine *e, const uint8_t *left, const uint8_t *right, int H, int W, int64_t stride_bytes,
+                int16_t *disp_out)
+{
+    if (!e || !left || !right || !disp_out) return set_err(SGM_ERR_INVALID_ARG, "null pointer");
+    if (H <= 0 || W < 2 || stride_bytes < W) return set_err(SGM_ERR_INVALID_ARG, "bad shape H=%d W=%d stride=%lld", H, W, (long long)stride_bytes);
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t npx = (size_t)H * W;
+    int rc;
+    if ((rc = e->in_left.ensure(npx)) || (rc = e->in_right.ensure(npx)) || (rc = e->disp_out.ensure(npx * 2))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(e->in_left.p, W, left, (size_t)stride_bytes, W, H, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpy2DAsync(e->in_right.p, W, right, (size_t)stride_bytes, W, H, hipMemcpyHostToDevice, e->stream));
+    if ((rc = run_compute(e, (const uint8_t *)e->in_left.p, (const uint8_t *)e->in_right.p, H, W, W, (int16_t *)e->disp_out.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(disp_out, e->disp_out.p, npx * 2, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t *rights, int H, int W,
+                      int16_t *disps_out, float *xyz_out, const double *Q16)
+{
+    if (!e || !lefts || !rights || !disps_out || N <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (xyz_out && !Q16) return set_err(SGM_ERR_INVALID_ARG, "xyz_out requested without Q");
+    if (H <= 0 || W < 2) return set_err(SGM_ERR_INVALID_ARG, "bad shape");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t npx = (size_t)H * W;
+    int rc;
+    if ((rc = e->in_left.ensure(npx)) || (rc = e->in_right.ensure(npx)) || (rc = e->disp_out.ensure(npx * 2))) return rc;
+    if (xyz_out && ((rc = e->f32.ensure(npx * 4)) || (rc = e->xyz.ensure(npx * 12)))) return rc;
+    for (int i = 0; i < N; i++) {
+        HIP_TRY(hipMemcpyAsync(e->in_left.p, lefts + (size_t)i * npx, npx, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->in_right.p, rights + (size_t)i * npx, npx, hipMemcpyHostToDevice, e->stream));
+        rc = sgm_pipeline_device(e, e->in_left.p, e->in_right.p, H, W, W, Q16, e->disp_out.p, xyz_out ? e->f32.p : nullptr,
+                                 xyz_out ? e->xyz.p : nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(disps_out + (size_t)i * npx, e->disp_out.p, npx * 2, hipMemcpyDeviceToHost, e->stream));
+        if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out + (size_t)i * npx * 3, e->xyz.p, npx * 12, hipMemcpyDeviceToHost, e->stream));
+        // pageable host memory: the copies above are synchronous with respect to the stream order
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_disp_to_float(sgm_engine *e, const int16_t *disp, int64_t n, float *out)
+{
+    if (!e || !disp || !out || n <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->disp_out.ensure((size_t)n * 2)) || (rc = e->f32.ensure((size_t)n * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->disp_out.p, disp, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
+    if ((rc = run_to_float(e, (const int16_t *)e->disp_out.p, n, (float *)e->f32.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, e->f32.p, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_reproject(sgm_engine *e, const float *disp, int H, int W, const double Q[16], int handle_missing, float *xyz_out)
+{
+    if (!e || !disp || !xyz_out || !Q || H <= 0 || W <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t npx = (size_t)H * W;
+    int rc;
+    if ((rc = e->f32.ensure(npx * 4)) || (rc = e->xyz.ensure(npx * 12))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->f32.p, disp, npx * 4, hipMemcpyHostToDevice, e->stream));
+    if ((rc = run_reproject(e, (const float *)e->f32.p, H, W, Q, handle_missing, (float *)e->xyz.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(xyz_out, e->xyz.p, npx * 12, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_valid_mask(sgm_engine *e, const float *xyz, const float *disp, int64_t n, uint8_t *mask)
+{
+    if (!e || !xyz || !disp || !mask || n <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->f32.ensure((size_t)n * 4)) || (rc = e->xyz.ensure((size_t)n * 12)) || (rc = e->mask.ensure((size_t)n))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->f32.p, disp, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->xyz.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
+    if ((rc = sgm_valid_mask_device(e, e->xyz.p, e->f32.p, n, e->mask.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(mask, e->mask.p, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_get_tap(sgm_engine *e, int tap, void *host_dst, int64_t bytes)
+{
+    if (!e || !host_dst) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (e->H <= 0) return set_err(SGM_ERR_INVALID_ARG, "no compute has run yet");
+    HIP_TRY(hipSetDevice(e->device));
+    const int64_t npx = (int64_t)e->H * e->W;
+    const int64_t vol = std::max<int64_t>(e->g.rowsz, 0) * e->H * 2;
+    const void *src = nullptr;
+    int64_t need = 0;
+    switch (tap) {
+    case SGM_TAP_COST: src = e->cost.p; need = vol; break;
+    case SGM_TAP_AGGR:
+        if (!e->keep_aggr) return set_err(SGM_ERR_INVALID_ARG, "SGM_TAP_AGGR needs SGM_OPT_KEEP_AGGR=1 before compute");
+        src = e->aggr.p; need = vol; break;
+    case SGM_TAP_DISP_RAW: src = e->disp_raw.p; need = npx * 2; break;
+    case SGM_TAP_DISP_MEDIAN: src = e->disp_med.p; need = npx * 2; break;
+    default: return set_err(SGM_ERR_INVALID_ARG, "unknown tap %d", tap);
+    }
+    if (bytes != need) return set_err(SGM_ERR_INVALID_ARG, "tap %d holds %lld bytes, caller passed %lld", tap, (long long)need, (long long)bytes);
+    if (need == 0) return SGM_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(host_dst, src, (size_t)need, hipMemcpyDeviceToHost));
+    return SGM_OK;
+}
+
+int sgm_get_stage_times(sgm_engine *e, sgm_stage_times *out)
+{
+    if (!e || !out) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (!e->profile) return set_err(SGM_ERR_INVALID_ARG, "SGM_OPT_PROFILE is off");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    out->n = e->nstages;
+    for (int i = 0; i < e->nstages; i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->events[i * 2], e->events[i * 2 + 1]));
+        out->name[i] = e->stage_names[i];
+        out->ms[i] = ms;
+        out->launches[i] = e->stage_launches[i];
+    }
+    return SGM_OK;
+}
+
+// SURVEY.md 8(d):  B_alg = 2HW (L,R in) + V (1 + 3 Np) + 2HW (disp out) + 8HW (median, speckle r+w)
+//                          [+ 16 HW reproject], V = 2 H W1 D bytes, Np = 5 (mode 0) or 8 (mode 1).
+int64_t sgm_algorithmic_bytes(const sgm_params *params, int H, int W, int with_reproject)
+{
+    Geom g;
+    if (!params || normalise(params, H, W, &g)) return -1;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t V = 2 * (int64_t)H * std::max(g.W1, 0) * g.D;
+    const int Np = g.mode == 1 ? 8 : 5;
+    int64_t b = 2 * HW + V * (1 + 3 * Np) + 2 * HW + 8 * HW;
+    if (with_reproject) b += 16 * HW;
+    return b;
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+"""Host-side mirror of the cv2 calls on the reference's "Run Disparity" path.
+
+    cv2.StereoSGBM_create(...)            /root/reference/main.ipynb:655-666  -> StereoSGBM_create
+    stereo.compute(imgL, imgR)            /root/reference/main.ipynb:668      -> StereoSGBM.compute
+    cv2.reprojectImageTo3D(disp, Q)       /root/reference/main.ipynb:697      -> reprojectImageTo3D
+
+Same names, keyword arguments, dtypes and error behaviour (a Python exception, so the
+`try/except Exception` of main.ipynb:696-701 still works), routed through the C ABI of
+include/sgm_hip.h into hand-written HIP for gfx950.  numpy arrays go through the host-pointer
+entry points (blocking, like cv2); torch CUDA tensors go through the device-pointer entry
+points and come back as torch tensors on the same device, without touching the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _lib
+
+STEREO_SGBM_MODE_SGBM = 0
+STEREO_SGBM_MODE_HH = 1
+STEREO_SGBM_MODE_SGBM_3WAY = 2
+STEREO_SGBM_MODE_HH4 = 3
+CV_32F = 5
+
+
+class error(Exception):
+    """Counterpart of cv2.error."""
+
+
+_PARAM_NAMES = ("minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff",
+                "preFilterCap", "uniquenessRatio", "speckleWindowSize", "speckleRange", "mode")
+
+_device = None
+
+
+def set_device(index: int) -> None:
+    """Select the GPU used by engines created afterwards (default: $LOCAL_RANK or 0)."""
+    global _device
+    _device = int(index)
+
+
+def get_device() -> int:
+    if _device is not None:
+        return _device
+    return int(os.environ.get("SGM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise error(f"sgm_hip error {rc}: {_lib.last_error()}")
+
+
+class Engine:
+    """Owns one sgm_engine handle (device buffers + stream) for a fixed parameter set."""
+
+    def __init__(self, params: dict, device: int | None = None, stream: int | None = None):
+        self._L = _lib.load()
+        self.params = dict(params)
+        self.device = get_device() if device is None else int(device)
+        p = _lib.SgmParams(*[int(params[n]) for n in _PARAM_NAMES])
+        self._p = p
+        h = C.c_void_p()
+        _check(self._L.sgm_create(C.byref(p), self.device, C.c_void_p(stream or 0), C.byref(h)))
+        self._h = h
+        self._fin = weakref.finalize(self, self._L.sgm_destroy, h)
+
+    # -- options / introspection
+    def set_option(self, opt: int, value: int) -> None:
+        _check(self._L.sgm_set_option(self._h, opt, int(value)))
+
+    def geometry(self, W: int):
+        a, b = C.c_int(), C.c_int()
+        _check(self._L.sgm_geometry(C.byref(self._p), W, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def algorithmic_bytes(self, H: int, W: int, with_reproject: bool = False) -> int:
+        return int(self._L.sgm_algorithmic_bytes(C.byref(self._p), H, W, int(with_reproject)))
+
+    def synchronize(self) -> None:
+        _check(self._L.sgm_synchronize(self._h))
+
+    def stage_times(self):
+        st = _lib.SgmStageTimes()
+        _check(self._L.sgm_get_stage_times(self._h, C.byref(st)))
+        return [(st.name[i].decode(), float(st.ms[i]), int(st.launches[i])) for i in range(st.n)]
+
+    def tap(self, which: int, H: int, W: int) -> np.ndarray:
+        if which in (_lib.SGM_TAP_COST, _lib.SGM_TAP_AGGR):
+            _, W1 = self.geometry(W)
+            out = np.empty((H, max(W1, 0), self.params["numDisparities"]), np.int16)
+        else:
+            out = np.empty((H, W), np.int16)
+        _check(self._L.sgm_get_tap(self._h, which, out.ctypes.data, out.nbytes))
+        return out
+
+    # -- host-pointer path
+    def compute_host(self, left: np.ndarray, right: np.ndarray) -> np.ndarray:
+        H, W = left.shape
+        disp = np.empty((H, W), np.int16)
+        if left.strides[0] != right.strides[0]:
+            right = np.ascontiguousarray(right)
+            left = np.ascontiguousarray(left)
+        _check(self._L.sgm_compute(self._h, left.ctypes.data, right.ctypes.data, H, W, left.strides[0],
+                                   disp.ctypes.data))
+        return disp
+
+    def compute_batch_host(self, lefts: np.ndarray, rights: np.ndarray, Q: np.ndarray | None = None):
+        N, H, W = lefts.shape
+        lefts = np.ascontiguousarray(lefts, np.uint8)
+        rights = np.ascontiguousarray(rights, np.uint8)
+        disps = np.empty((N, H, W), np.int16)
+        xyz = None
+        qp = None
+        if Q is not None:
+            Q = np.ascontiguousarray(Q, np.float64)
+            xyz = np.empty((N, H, W, 3), np.float32)
+            qp = Q.ctypes.data
+        _check(self._L.sgm_compute_batch(self._h, N, lefts.ctypes.data, rights.ctypes.data, H, W, disps.ctypes.data,
+                                         xyz.ctypes.data if xyz is not None else None, qp))
+        return (disps, xyz) if Q is not None else disps
+
+    def disp_to_float_host(self, disp: np.ndarray) -> np.ndarray:
+        disp = np.ascontiguousarray(disp, np.int16)
+        out = np.empty(disp.shape, np.float32)
+        _check(self._L.sgm_disp_to_float(self._h, disp.ctypes.data, disp.size, out.ctypes.data))
+        return out
+
+    def reproject_host(self, disp: np.ndarray, Q: np.ndarray, handle_missing: bool) -> np.ndarray:
+        H, W = disp.shape
+        out = np.empty((H, W, 3), np.float32)
+        _check(self._L.sgm_reproject(self._h, disp.ctypes.data, H, W, Q.ctypes.data, int(handle_missing),
+                                     out.ctypes.data))
+        return out
+
+    def valid_mask_host(self, xyz: np.ndarray, disp: np.ndarray) -> np.ndarray:
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        disp = np.ascontiguousarray(disp, np.float32)
+        out = np.empty(disp.shape, np.uint8)
+        _check(self._L.sgm_valid_mask(self._h, xyz.ctypes.data, disp.ctypes.data, disp.size, out.ctypes.data))
+        return out.astype(bool)
+
+    # -- device-pointer path (raw addresses; torch only supplies the memory)
+    def compute_device(self, d_left: int, d_right: int, H: int, W: int, stride: int, d_disp: int) -> None:
+        _check(self._L.sgm_compute_device(self._h, d_left, d_right, H, W, stride, d_disp))
+
+    def pipeline_device(self, d_left: int, d_right: int, H: int, W: int, stride: int, Q: np.ndarray | None,
+                        d_disp: int | None, d_dispf: int | None, d_xyz: int | None) -> None:
+        qp = None
+        if Q is not None:
+            Q = np.ascontiguousarray(Q, np.float64)
+            qp = Q.ctypes.data
+        _check(self._L.sgm_pipeline_device(self._h, d_left, d_right, H, W, stride, qp, d_disp, d_dispf, d_xyz))
+
+    def disp_to_float_device(self, d_disp: int, n: int, d_out: int) -> None:
+        _check(self._L.sgm_disp_to_float_device(self._h, d_disp, n, d_out))
+
+    def reproject_device(self, d_disp: int, H: int, W: int, Q: np.ndarray, handle_missing: bool, d_xyz: int) -> None:
+        Q = np.ascontiguousarray(Q, np.float64)
+        _check(self._L.sgm_reproject_device(self._h, d_disp, H, W, Q.ctypes.data, int(handle_missing), d_xyz))
+
+    def valid_mask_device(self, d_xyz: int, d_disp: int, n: int, d_mask: int) -> None:
+        _check(self._L.sgm_valid_mask_device(self._h, d_xyz, d_disp, n, d_mask))
+
+
+# The notebook builds a matcher per call and throws it away (main.ipynb:655-668); engines are
+# cached per (parameters, device) so device buffers survive between such calls.
+_engine_cache: dict = {}
+_CACHE_MAX = 4
+
+
+def get_engine(params: dict, device: int | None = None) -> Engine:
+    dev = get_device() if device is None else int(device)
+    key = (tuple(int(params[n]) for n in _PARAM_NAMES), dev)
+    e = _engine_cache.get(key)
+    if e is None:
+        if len(_engine_cache) >= _CACHE_MAX:
+            _engine_cache.pop(next(iter(_engine_cache)))
+        e = Engine(params, dev)
+        _engine_cache[key] = e
+    return e
+
+
+def clear_engine_cache() -> None:
+    _engine_cache.clear()
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class StereoSGBM:
+    """Mirror of cv2.StereoSGBM (the subset of the interface the reference exercises, plus the
+    parameter getters/setters of the cv2 class)."""
+
+    def __init__(self, **kw):
+        self._p = {n: 0 for n in _PARAM_NAMES}
+        self._p.update(numDisparities=16, blockSize=3)
+        for k, v in kw.items():
+            if k not in self._p:
+                raise TypeError(f"StereoSGBM_create() got an unexpected keyword argument '{k}'")
+            self._p[k] = int(v)
+
+    # cv2-style accessors
+    def __getattr__(self, name):
+        if name.startswith(("get", "set")) and len(name) > 3:
+            field = name[3].lower() + name[4:]
+            field = {"mode": "mode", "p1": "P1", "p2": "P2"}.get(field, field)
+            if field in self._p:
+                if name.startswith("get"):
+                    return lambda: self._p[field]
+                return lambda v: self._p.__setitem__(field, int(v))
+        raise AttributeError(name)
+
+    def compute(self, left, right):
+        """int16 (H, W) disparity * 16, invalid = (minDisparity - 1) * 16  (main.ipynb:668)."""
+        if self._p["mode"] not in (STEREO_SGBM_MODE_SGBM, STEREO_SGBM_MODE_HH):
+            raise error("StereoSGBM.compute: only MODE_SGBM and MODE_HH are implemented "
+                        "(the reference never selects MODE_SGBM_3WAY / MODE_HH4)")
+        if _is_torch(left) or _is_torch(right):
+            return self._compute_torch(left, right)
+        left, right = np.asarray(left), np.asarray(right)
+        # upstream: CV_Assert(left.size() == right.size() && left.type() == right.type() && depth == CV_8U)
+        if left.shape != right.shape or left.dtype != right.dtype or left.dtype != np.uint8:
+            raise error("StereoSGBM.compute: (-215:Assertion failed) left.size() == right.size() && "
+                        "left.type() == right.type() && left.depth() == CV_8U")
+        if left.ndim == 3 and left.shape[2] == 1:
+            left, right = left[:, :, 0], right[:, :, 0]
+        if left.ndim != 2:
+            raise error("StereoSGBM.compute: only single-channel 8-bit images are supported "
+                        "(the reference reads its pairs with IMREAD_GRAYSCALE, main.ipynb:362-363)")
+        if left.shape[0] == 0 or left.shape[1] == 0:
+            raise error("StereoSGBM.compute: empty image")
+        if left.strides[1] != 1 or left.strides[0] < left.shape[1]:
+            left = np.ascontiguousarray(left)
+        if right.strides[1] != 1 or right.strides[0] < right.shape[1]:
+            right = np.ascontiguousarray(right)
+        if left.shape[1] < 2:
+            raise error("StereoSGBM.compute: image width < 2")
+        return get_engine(self._p).compute_host(left, right)
+
+    def _compute_torch(self, left, right):
+        import torch
+        if not (_is_torch(left) and _is_torch(right)) or not left.is_cuda or not right.is_cuda:
+            raise error("StereoSGBM.compute: torch inputs must both be CUDA (HIP) tensors")
+        if left.shape != right.shape or left.dtype != torch.uint8 or right.dtype != torch.uint8 or left.dim() != 2:
+            raise error("StereoSGBM.compute: (-215:Assertion failed) left.size() == right.size() && "
+                        "left.type() == right.type() && left.depth() == CV_8U")
+        left, right = left.contiguous(), right.contiguous()
+        H, W = left.shape
+        dev = left.device.index or 0
+        eng = get_engine(self._p, dev)
+        out = torch.empty((H, W), dtype=torch.int16, device=left.device)
+        # the engine runs on its own stream: order it after torch's current stream and wait for it
+        torch.cuda.current_stream(left.device).synchronize()
+        eng.compute_device(left.data_ptr(), right.data_ptr(), H, W, W, out.data_ptr())
+        eng.synchronize()
+        return out
+
+
+def StereoSGBM_create(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0,
+                      preFilterCap=0, uniquenessRatio=0, speckleWindowSize=0, speckleRange=0,
+                      mode=STEREO_SGBM_MODE_SGBM) -> StereoSGBM:
+    """Same signature and defaults as cv2.StereoSGBM_create (OpenCV 4.11)."""
+    return StereoSGBM(minDisparity=minDisparity, numDisparities=numDisparities, blockSize=blockSize, P1=P1, P2=P2,
+                      disp12MaxDiff=disp12MaxDiff, preFilterCap=preFilterCap, uniquenessRatio=uniquenessRatio,
+                      speckleWindowSize=speckleWindowSize, speckleRange=speckleRange, mode=mode)
+
+
+_DEFAULT = dict(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0, preFilterCap=0,
+                uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=0)
+
+
+def reprojectImageTo3D(disparity, Q, _3dImage=None, handleMissingValues=False, ddepth=-1):
+    """float32 (H, W, 3) = Q . [x, y, d, 1] / W   (main.ipynb:697)."""
+    if ddepth not in (-1, CV_32F):
+        raise error("reprojectImageTo3D: only ddepth=-1 / CV_32F is implemented (the reference uses the default)")
+    Q = np.asarray(Q)
+    if Q.shape != (4, 4):
+        raise error("reprojectImageTo3D: (-215:Assertion failed) Q.size() == Size(4,4)")
+    Q = np.ascontiguousarray(Q, np.float64)
+    if _is_torch(disparity):
+        import torch
+        if not disparity.is_cuda or disparity.dim() != 2:
+            raise error("reprojectImageTo3D: torch disparity must be a 2-D CUDA tensor")
+        d = disparity.to(torch.float32).contiguous()
+        H, W = d.shape
+        eng = get_engine(_DEFAULT, d.device.index or 0)
+        out = torch.empty((H, W, 3), dtype=torch.float32, device=d.device)
+        torch.cuda.current_stream(d.device).synchronize()
+        eng.reproject_device(d.data_ptr(), H, W, Q, bool(handleMissingValues), out.data_ptr())
+        eng.synchronize()
+        return out
+    d = np.asarray(disparity)
+    # upstream accepts CV_8UC1, CV_16SC1, CV_32SC1, CV_32FC1 and converts each row to float
+    if d.ndim != 2 or d.dtype not in (np.uint8, np.int16, np.int32, np.float32):
+        raise error("reprojectImageTo3D: (-215:Assertion failed) stype == CV_8UC1 || stype == CV_16SC1 || "
+                    "stype == CV_32SC1 || stype == CV_32FC1")
+    if d.size == 0:
+        raise error("reprojectImageTo3D: empty disparity")
+    d = np.ascontiguousarray(d, np.float32)
+    return get_engine(_DEFAULT).reproject_host(d, Q, bool(handleMissingValues))

@@ -1,0 +1,80 @@
+"""CPU-side checks of the C ABI: the library loads, exports every declared symbol, and fails
+loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from stereo_reconstruction_cv_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "sgm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgm_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_and_binding_list_agree():
+    assert _declared_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    for name in _declared_symbols():
+        assert hasattr(L, name), name
+    assert L.sgm_abi_version() == 1
+
+
+def test_parameter_validation_and_geometry_need_no_gpu():
+    L = _lib.load()
+    p = _lib.SgmParams(0, 256, 7, 0, 0, 0, 0, 0, 0, 0, 0)
+    a, b = C.c_int(), C.c_int()
+    assert L.sgm_geometry(C.byref(p), 3840, C.byref(a), C.byref(b)) == 0
+    assert (a.value, b.value) == (256, 3584)
+    # C3 (mode HH) 99.2 GB, C5 (5 paths) 63.5 GB + reproject
+    p.mode = 1
+    assert abs(L.sgm_algorithmic_bytes(C.byref(p), 2160, 3840, 0) / 1e9 - 99.2) < 0.2
+    p.mode = 0
+    assert abs(L.sgm_algorithmic_bytes(C.byref(p), 2160, 3840, 1) / 1e9 - 63.6) < 0.2
+    bad = _lib.SgmParams(0, 24, 7, 0, 0, 0, 0, 0, 0, 0, 0)
+    assert L.sgm_geometry(C.byref(bad), 100, None, None) == -4           # SGM_ERR_UNSUPPORTED
+    assert b"divisible by 16" in L.sgm_last_error()
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import stereo_reconstruction_cv_amd as cv
+    with pytest.raises(cv.error, match="no CPU fallback"):
+        cv.StereoSGBM_create(numDisparities=16).compute(np.zeros((8, 40), np.uint8), np.zeros((8, 40), np.uint8))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "stereo_reconstruction_cv_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "liboracle" not in src, f
+
+
+def test_median_network_is_a_median():
+    # zero-one principle on the 19-exchange network used by k_median3 (kernels_post.h)
+    seq = [(1, 2), (4, 5), (7, 8), (0, 1), (3, 4), (6, 7), (1, 2), (4, 5), (7, 8), (0, 3), (5, 8), (4, 7),
+           (3, 6), (1, 4), (2, 5), (4, 7), (4, 2), (6, 4), (4, 2)]
+    src = open(os.path.join(ROOT, "stereo_reconstruction_cv_amd", "csrc", "kernels_post.h")).read()
+    got = [(int(a), int(b)) for a, b in re.findall(r"cswap\(p(\d), p(\d)\)", src)]
+    assert got == seq
+    for bits in range(512):
+        v = [(bits >> i) & 1 for i in range(9)]
+        want = sorted(v)[4]
+        for a, b in seq:
+            lo, hi = min(v[a], v[b]), max(v[a], v[b])
+            v[a], v[b] = lo, hi
+        assert v[4] == want

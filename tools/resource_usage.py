@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Summarise hipcc -Rpass-analysis=kernel-resource-usage output (one line per kernel)."""
+import re
+import subprocess
+import sys
+
+path = sys.argv[1] if len(sys.argv) > 1 else "stereo_reconstruction_cv_amd/csrc/resource_usage.txt"
+rows, cur = [], None
+for line in open(path):
+    m = re.search(r"Function Name: (\S+)", line)
+    if m:
+        name = m.group(1)
+        try:
+            name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+        except OSError:
+            pass
+        cur = {"name": re.sub(r"\(.*", "", name)}
+        rows.append(cur)
+        continue
+    m = re.search(r"remark: \s*([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+    if m and cur is not None:
+        cur[m.group(1).strip()] = int(m.group(2))
+for r in rows:
+    print(f"{r['name']:<48} vgpr={r.get('VGPRs', '?'):>3} agpr={r.get('AGPRs', '?'):>3} sgpr={r.get('SGPRs', '?'):>3} "
+          f"scratch={r.get('ScratchSize', '?'):>4} occ={r.get('Occupancy', '?')} lds={r.get('LDS Size', '?')}")
