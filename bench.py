@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: dense stereo disparity throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+A "step" = one pass of the hot path (SGBM compute -> float scaling -> reprojectImageTo3D) over
+one batch of synthetic rectified pairs that is already resident in HBM.  For N > 1 the driver
+launches one rank per GPU with torch.distributed.run; frames are sharded by rank with no
+data-path collective (weak scaling), the timed region is bracketed by barrier + synchronize on
+both sides and the maximum over ranks is reported.  Rank 0 prints ONE JSON line.
+
+Default workload "c3c5": 3840x2160, D=256, blockSize=7, MODE_HH (8 paths) + LR check +
+sub-pixel + median + speckle + reprojection to XYZ, i.e. the union of BASELINE.json configs[2]
+and configs[4]; the other configs are selectable with --workload and are parity-test cases.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+NB = dict(disp12MaxDiff=1, preFilterCap=63, uniquenessRatio=10, speckleWindowSize=100, speckleRange=32)
+
+WORKLOADS = {
+    # name: (H, W, D, blockSize, mode, pairs per GPU per step, reproject, description)
+    "c1": (720, 1280, 64, 5, 0, 1, False, "1280x720 D=64 bs=5 5-path (BASELINE configs[0])"),
+    "c2": (2160, 3840, 128, 7, 0, 1, False, "3840x2160 D=128 bs=7 5-path (configs[1])"),
+    "c3": (2160, 3840, 256, 7, 1, 1, False, "3840x2160 D=256 bs=7 8-path (configs[2])"),
+    "c4": (1080, 1920, 128, 7, 0, 8, False, "8x 1920x1080 D=128 bs=7 5-path per GPU (configs[3])"),
+    "c5": (2160, 3840, 256, 7, 0, 1, True, "3840x2160 D=256 bs=7 5-path + reproject (configs[4])"),
+    "c3c5": (2160, 3840, 256, 7, 1, 1, True,
+             "3840x2160 D=256 bs=7 MODE_HH 8-path + LR + subpixel + median + speckle + reprojectImageTo3D"),
+    "nb": (2160, 3840, 16, 11, 0, 1, True, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
+}
+
+
+def sgbm_params(D, bs, mode):
+    return dict(minDisparity=0, numDisparities=D, blockSize=bs, P1=8 * 3 * bs * bs, P2=32 * 3 * bs * bs, mode=mode, **NB)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline runs (0 = auto)")
+    ap.add_argument("--verify", action="store_true", help="also run the oracle on the full frame and compare")
+    ap.add_argument("--stages", action="store_true", help="print the per-stage HIP-event table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import stereo_reconstruction_cv_amd as cv
+    from stereo_reconstruction_cv_amd import _lib, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    H, W, D, bs, mode, ppg, with_xyz, desc = WORKLOADS[args.workload]
+    p = sgbm_params(D, bs, mode)
+    Q = synth.default_Q(W)
+
+    # ---- inputs resident in HBM before the timed region ----
+    pairs = [synth.make_pair(H, W, D, seed=1234 + rank * ppg + i)[:2] for i in range(ppg)]
+    d_left = [torch.from_numpy(a).to(dev) for a, _ in pairs]
+    d_right = [torch.from_numpy(b).to(dev) for _, b in pairs]
+    d_disp = [torch.empty((H, W), dtype=torch.int16, device=dev) for _ in range(ppg)]
+    d_dispf = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(ppg)] if with_xyz else None
+    d_xyz = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(ppg)] if with_xyz else None
+    torch.cuda.synchronize(dev)
+
+    eng = cv.Engine(p, device=local_rank)
+    eng.set_option(_lib.SGM_OPT_PROFILE, 1)
+
+    def step():
+        acc = []
+        for i in range(ppg):
+            eng.pipeline_device(d_left[i].data_ptr(), d_right[i].data_ptr(), H, W, W, Q if with_xyz else None,
+                                d_disp[i].data_ptr(), d_dispf[i].data_ptr() if with_xyz else None,
+                                d_xyz[i].data_ptr() if with_xyz else None)
+            acc.append(eng.stage_times())  # HIP events on the engine's stream; synchronises it
+        return acc
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stage_acc = []
+    for _ in range(args.steps):
+        stage_acc.extend(step())
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-stage HIP-event durations (this rank) ----
+    names = [n for n, _, _ in stage_acc[0]]
+    ms = np.array([[m for _, m, _ in st] for st in stage_acc])  # [frames][stages]
+    mean_ms = ms.mean(axis=0)
+    if args.stages and rank == 0:
+        for n, m in zip(names, mean_ms):
+            print(f"  {n:<14s} {m:9.4f} ms", file=sys.stderr)
+        print(f"  {'sum':<14s} {mean_ms.sum():9.4f} ms   wall/frame {dt / args.steps / ppg * 1e3:9.4f} ms", file=sys.stderr)
+
+    # dominant kernel: the accumulate instance of the path kernel (k_path<NP, *, PATH_ACCUM>),
+    # one launch per stage; algorithmic bytes per launch = 3 V (read C, read S, write S).
+    _, W1 = eng.geometry(W)
+    V = 2 * H * W1 * D
+    accum = [i for i, n in enumerate(names) if n.startswith("path_") and n not in ("path_S", "path_W_wta")]
+    k_ms = float(mean_ms[accum].mean())
+    achieved = 3 * V / (k_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            if rec.get("workload") == args.workload:
+                traffic = rec.get("traffic_bytes_per_launch")
+        except (OSError, ValueError):
+            traffic = None
+
+    frames = args.steps * ppg * world
+    mdisp = frames * H * W * D / dt / 1e6
+    alg_bytes = eng.algorithmic_bytes(H, W, with_xyz)
+
+    out = {
+        "metric": "Mdisparities/s",
+        "value": mdisp,
+        "unit": "Mdisparities/s (H*W*D per second, whole job)",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int16",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}", "height": H, "width": W, "numDisparities": D,
+                   "blockSize": bs, "mode": "MODE_HH" if mode else "MODE_SGBM", "pairs_per_gpu_per_step": ppg,
+                   "global_pairs_per_step": ppg * world, "parallelism": f"frame-sharded x{world}, no data-path collective"},
+        "pairs_per_s": frames / dt,
+        "algorithmic_GBps_whole_step": alg_bytes * ppg * world / (dt / args.steps) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": f"k_path<NP={2 if 128 < D <= 256 else (1 if D <= 128 else 4)},PATH_ACCUM>",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": 3 * V, "avg_launch_ms": k_ms,
+                     "launches_per_step": len(accum) * ppg},
+        "stage_ms": {n: float(m) for n, m in zip(names, mean_ms)},
+    }
+
+    # ---- CPU baseline: the oracle (a scalar single-thread port), bounded sample, rank 0 at N=1 ----
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as O  # test infrastructure; timed here only as the CPU baseline
+        rows = args.cpu_rows or min(H, max(64, int(1080 * (3840 * 256) / (W * D))))
+        rows = min(rows, H)
+        l, r = pairs[0][0][:rows], pairs[0][1][:rows]
+        O.lib()
+        t0 = time.perf_counter()
+        want = O.sgbm_compute(l, r, **p)
+        if with_xyz:
+            O.reproject(O.disp_to_float(want), Q)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": rows * W * D / cdt / 1e6, "unit": "Mdisparities/s", "cores": 1, "kind": "port",
+            "sample": f"rows 0..{rows - 1} of the same {W}x{H} pair (full width, D={D}, same parameters), "
+                      f"{cdt:.1f} s on one host core; OpenCV-4.11-equivalent C restatement, not cv2",
+        }
+        out["speedup_vs_cpu_baseline"] = mdisp / out["cpu_baseline"]["value"]
+        if args.verify:
+            t0 = time.perf_counter()
+            full, taps = O.sgbm_compute(pairs[0][0], pairs[0][1], taps=False, **p), None
+            got = d_disp[0].cpu().numpy()
+            nbad = int((got != full).sum())
+            out["verify"] = {"full_frame_mismatches": nbad, "pixels": int(got.size),
+                             "valid_fraction": float((got >= 0).mean()), "oracle_s": time.perf_counter() - t0}
+            if with_xyz:
+                ref = O.reproject(O.disp_to_float(full), Q)
+                x = d_xyz[0].cpu().numpy()
+                fin = np.isfinite(ref)
+                out["verify"]["xyz_finite_mask_equal"] = bool(np.array_equal(np.isfinite(x), fin))
+                out["verify"]["xyz_max_rel_err"] = float(np.max(np.abs(x[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-30))) if fin.any() else 0.0
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

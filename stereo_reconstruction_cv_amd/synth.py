@@ -33,14 +33,17 @@ def _octave(xs: np.ndarray, ys: np.ndarray, cell: int, seed: int, salt: int) -> 
     """Bilinear interpolation (integer weights) of 8-bit lattice noise with the given cell size."""
     ix, tx = np.divmod(xs, cell)
     iy, ty = np.divmod(ys, cell)
-
-    def lat(a, b):
-        return (_hash2(a, b, seed, salt) >> np.uint64(56)).astype(np.int64)  # 0..255
-
-    a = lat(ix, iy)
-    b = lat(ix + 1, iy)
-    c = lat(ix, iy + 1)
-    d = lat(ix + 1, iy + 1)
+    # hash only the lattice points that are touched, then gather
+    ix0, iy0 = int(ix.min()), int(iy.min())
+    gx = np.arange(ix0, int(ix.max()) + 2, dtype=np.int64)
+    gy = np.arange(iy0, int(iy.max()) + 2, dtype=np.int64)
+    GY, GX = np.meshgrid(gy, gx, indexing="ij")
+    lat = (_hash2(GX, GY, seed, salt) >> np.uint64(56)).astype(np.int64)  # 0..255
+    jx, jy = ix - ix0, iy - iy0
+    a = lat[jy, jx]
+    b = lat[jy, jx + 1]
+    c = lat[jy + 1, jx]
+    d = lat[jy + 1, jx + 1]
     top = a * (cell - tx) + b * tx
     bot = c * (cell - tx) + d * tx
     return (top * (cell - ty) + bot * ty) // (cell * cell)
@@ -81,8 +84,11 @@ def make_pair(H: int, W: int, D: int, seed: int = 1234):
     base = texture(H, W, seed, 0)
     src = xs + g
     warped = texture(H, W, seed, 0, x0=src)
-    other = texture(H, W, seed, 7)
-    right = np.where(src < W, warped, other)
+    right = warped
+    out = src >= W                      # scene point outside the left view: unrelated texture
+    if out.any():
+        right = warped.copy()
+        right[out] = texture(H, W, seed, 7)[out]
     nl = (_hash2(xs, ys, seed, 101) >> np.uint64(40)).astype(np.int64) % 5 - 2
     nr = (_hash2(xs, ys, seed, 202) >> np.uint64(40)).astype(np.int64) % 5 - 2
     left = np.clip(base + nl, 0, 255).astype(np.uint8)
