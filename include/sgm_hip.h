@@ -10,6 +10,10 @@
  *   sgm_disp_to_float    <- .astype(np.float32)/16 ; mask = >0 ; multiply      main.ipynb:668-670
  *   sgm_reproject        <- cv2.reprojectImageTo3D(disparity_map, Q)           main.ipynb:697
  *   sgm_valid_mask       <- ~isnan(X) & ~isinf(X) & (disparity_map > 0)        main.ipynb:726-730
+ *   sgm_median3x3,
+ *   sgm_filter_speckles  <- the two post-filters .compute() applies internally (upstream
+ *                           medianBlur(disp,3) / filterSpeckles; cv2.medianBlur /
+ *                           cv2.filterSpeckles are their public faces)        main.ipynb:664-665,668
  *   sgm_pipeline_device  <- cell c13: compute -> scale/mask -> reproject       main.ipynb:781,790
  *   sgm_compute_batch    <- the same, over N independent pairs (frame sharding unit)
  *
@@ -104,6 +108,9 @@ int sgm_disp_to_float(sgm_engine *e, const int16_t *disp, int64_t n, float *out)
 int sgm_reproject(sgm_engine *e, const float *disp, int H, int W, const double Q[16],
                   int handle_missing, float *xyz_out /* H*W*3 */);
 int sgm_valid_mask(sgm_engine *e, const float *xyz, const float *disp, int64_t n, uint8_t *mask);
+int sgm_median3x3(sgm_engine *e, const int16_t *src, int H, int W, int16_t *dst);
+int sgm_filter_speckles(sgm_engine *e, int16_t *img /* in place */, int H, int W, int newVal,
+                        int maxSpeckleSize, int maxDiff);
 int sgm_get_tap(sgm_engine *e, int tap, void *host_dst, int64_t bytes);
 
 /* ---- device-pointer entry points (asynchronous on the engine's stream) ---- */

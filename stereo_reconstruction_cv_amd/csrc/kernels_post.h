@@ -91,24 +91,30 @@ __global__ __launch_bounds__(256) void k_median3(const int16_t *__restrict__ src
 }
 
 // ------------------------------------------------------------------------------------------
-// Speckle filter as lock-free union-find over the 4-neighbour graph (A.8): the component
-// partition, hence the output, does not depend on the traversal order upstream uses.
-// Parent links only ever decrease (atomicMin), so a stale value is still an ancestor; the loads
-// are agent-scope (L2) all the same: a CU's L1 is never refreshed by other CUs' atomics.
+// Speckle filter (A.8) as connected components over horizontal RUNS: a run is a maximal stretch
+// of one row whose neighbouring pixels are linked (both != newVal, |a-b| <= maxDiff).  Every
+// pixel of a run points at the run's first pixel; first pixels form a lock-free union-find
+// forest (links only ever decrease, atomicMin) joined where runs of adjacent rows touch.  The
+// component partition, hence the output, does not depend on the traversal order upstream uses.
+//
+//   label[i] : -1 invalid | i's run start (non-start pixels, immutable) | parent link (starts)
+//   rlen[s]  : length of the run starting at s          csz[r] : pixels of the component rooted at r
 __device__ __forceinline__ int uf_load(const int *L, int a)
 {
+    // agent scope: a CU's L1 is never refreshed by other CUs' atomics
     return __hip_atomic_load(L + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ int uf_find(const int *L, int a)
+__device__ __forceinline__ int uf_find(int *L, int a)
 {
     int p = uf_load(L, a);
     while (p != a) {
+        const int gp = uf_load(L, p);
+        if (gp != p) atomicMin(&L[a], gp);  // path halving; any ancestor is a valid parent
         a = p;
-        p = uf_load(L, a);
+        p = gp;
     }
     return a;
 }
-
 __device__ __forceinline__ void uf_union(int *L, int a, int b)
 {
     bool done;
@@ -129,16 +135,70 @@ __device__ __forceinline__ void uf_union(int *L, int a, int b)
     } while (!done);
 }
 
-__global__ __launch_bounds__(256) void k_ccl_init(const int16_t *__restrict__ img, int *__restrict__ label,
-                                                  int *__restrict__ size, int64_t n, int newVal)
+__device__ __forceinline__ bool linked(int a, int b, int newVal, int maxDiff)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    label[i] = img[i] != newVal ? (int)i : -1;
-    size[i] = 0;
+    return a != newVal && b != newVal && abs(a - b) <= maxDiff;
 }
 
+// one wave per row: run starts by an inclusive prefix-max of "x where a run begins"
+__global__ __launch_bounds__(64) void k_ccl_rows(const int16_t *__restrict__ img, int *__restrict__ label,
+                                                 int *__restrict__ rlen, int *__restrict__ csz, int W,
+                                                 int newVal, int maxDiff)
+{
+    const int y = blockIdx.x, lane = threadIdx.x;
+    const int16_t *row = img + (int64_t)y * W;
+    const int64_t base = (int64_t)y * W;
+    int carry = -1;  // start of the run the previous chunk ended in
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool in = x < W;
+        const int v = in ? row[x] : newVal;
+        const int vl = (in && x > 0) ? row[x - 1] : newVal;
+        const int vr = (in && x < W - 1) ? row[x + 1] : newVal;
+        const bool valid = v != newVal;
+        const bool starts = valid && !linked(v, vl, newVal, maxDiff);
+        int s = starts ? x : -1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(s, o);
+            if (lane >= o) s = max(s, t);
+        }
+        s = max(s, carry);
+        if (in) {
+            label[base + x] = valid ? (int)(base + s) : -1;
+            csz[base + x] = 0;
+            if (valid && !linked(v, vr, newVal, maxDiff)) rlen[base + s] = x - s + 1;  // run ends here
+        }
+        carry = __shfl(s, 63);
+    }
+}
+
+// join runs of adjacent rows; one union per maximal stretch of vertical links between two runs
 __global__ __launch_bounds__(256) void k_ccl_merge(const int16_t *__restrict__ img, int *label, int H, int W,
+                                                   int newVal, int maxDiff)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y == 0) return;
+    const int64_t i = (int64_t)y * W + x;
+    const int v = img[i], u = img[i - W];
+    if (!linked(v, u, newVal, maxDiff)) return;
+    bool need = x == 0;
+    if (!need) {
+        const int vl = img[i - 1], ul = img[i - W - 1];
+        // the stretch starts here if the left column is not linked the same way
+        need = !linked(v, vl, newVal, maxDiff) || !linked(u, ul, newVal, maxDiff) || !linked(vl, ul, newVal, maxDiff);
+    }
+    if (!need) return;
+    const bool vs = x == 0 || !linked(v, img[i - 1], newVal, maxDiff);
+    const bool us = x == 0 || !linked(u, img[i - W - 1], newVal, maxDiff);
+    const int a = vs ? (int)i : label[i];          // run starts (non-start labels are immutable)
+    const int b = us ? (int)(i - W) : label[i - W];
+    uf_union(label, a, b);
+}
+
+// per run: add its length to its component's root and point the run start at the root
+__global__ __launch_bounds__(256) void k_ccl_count(const int16_t *__restrict__ img, int *label,
+                                                   const int *__restrict__ rlen, int *__restrict__ csz, int H, int W,
                                                    int newVal, int maxDiff)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -146,42 +206,22 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const int16_t *__restrict__ i
     const int64_t i = (int64_t)y * W + x;
     const int v = img[i];
     if (v == newVal) return;
-    if (x > 0) {
-        const int u = img[i - 1];
-        if (u != newVal && abs(v - u) <= maxDiff) uf_union(label, (int)i, (int)(i - 1));
-    }
-    if (y > 0) {
-        const int u = img[i - W];
-        if (u != newVal && abs(v - u) <= maxDiff) uf_union(label, (int)i, (int)(i - W));
-    }
-}
-
-__global__ __launch_bounds__(256) void k_ccl_count(int *label, int *__restrict__ size, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (label[i] < 0) return;
+    if (x > 0 && linked(v, img[i - 1], newVal, maxDiff)) return;  // not a run start
     const int r = uf_find(label, (int)i);
-    label[i] = r;  // any concurrent reader still sees an ancestor of its root
-    atomicAdd(&size[r], 1);
+    atomicAdd(&csz[r], rlen[i]);
 }
 
-__global__ __launch_bounds__(256) void k_ccl_apply(int16_t *__restrict__ img, const int *__restrict__ label,
-                                                   const int *__restrict__ size, int64_t n, int newVal,
-                                                   int maxSpeckleSize)
+__global__ __launch_bounds__(256) void k_ccl_apply(int16_t *__restrict__ img, int *label,
+                                                   const int *__restrict__ csz, int H, int W, int newVal,
+                                                   int maxDiff, int maxSpeckleSize)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int r = label[i];
-    if (r < 0) return;
-    // label[i] is i's root or (if written before a later flatten) an ancestor; roots are fixed
-    // points, so walk to be safe
-    int a = r, p = label[a];
-    while (p != a) {
-        a = p;
-        p = label[a];
-    }
-    if (size[a] <= maxSpeckleSize) img[i] = (int16_t)newVal;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int64_t i = (int64_t)y * W + x;
+    const int l = label[i];
+    if (l < 0) return;
+    const int r = uf_find(label, l);  // l is i itself or i's run start
+    if (csz[r] <= maxSpeckleSize) img[i] = (int16_t)newVal;
 }
 
 // ------------------------------------------------------------------------------------------

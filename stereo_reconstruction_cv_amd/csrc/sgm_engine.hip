@@ -85,7 +85,7 @@ struct sgm_engine {
     DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
     DevBuf wta;                         // uint2 [H][W]
     DevBuf disp_raw, disp_med, disp_out;  // int16 [H][W]
-    DevBuf label, csize;                // int32 [H][W] each
+    DevBuf label, csize, rlen;          // int32 [H][W] each
     DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
 
     // profiling
@@ -208,8 +208,22 @@ static int ensure_buffers(sgm_engine *e, int H, int W)
     if ((rc = e->wta.ensure(npx * 8))) return rc;
     if ((rc = e->disp_raw.ensure(npx * 2))) return rc;
     if ((rc = e->disp_med.ensure(npx * 2))) return rc;
-    if ((rc = e->label.ensure(npx * 4))) return rc;
-    if ((rc = e->csize.ensure(npx * 4))) return rc;
+    return SGM_OK;
+}
+
+static int run_speckles(sgm_engine *e, int16_t *d_img, int H, int W, int newVal, int maxSpeckleSize, int maxDiff)
+{
+    const size_t npx = (size_t)H * W;
+    int rc;
+    if ((rc = e->label.ensure(npx * 4)) || (rc = e->csize.ensure(npx * 4)) || (rc = e->rlen.ensure(npx * 4))) return rc;
+    int *label = (int *)e->label.p, *csz = (int *)e->csize.p, *rlen = (int *)e->rlen.p;
+    hipStream_t st = e->stream;
+    dim3 g2((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_ccl_rows, dim3(H), dim3(64), 0, st, (const int16_t *)d_img, label, rlen, csz, W, newVal, maxDiff);
+    hipLaunchKernelGGL(k_ccl_merge, g2, dim3(256), 0, st, (const int16_t *)d_img, label, H, W, newVal, maxDiff);
+    hipLaunchKernelGGL(k_ccl_count, g2, dim3(256), 0, st, (const int16_t *)d_img, label, (const int *)rlen, csz, H, W, newVal, maxDiff);
+    hipLaunchKernelGGL(k_ccl_apply, g2, dim3(256), 0, st, d_img, label, (const int *)csz, H, W, newVal, maxDiff, maxSpeckleSize);
+    KCHECK();
     return SGM_OK;
 }
 
@@ -347,15 +361,9 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
     int nl = 1;
     HIP_TRY(hipMemcpyAsync(d_disp, med, (size_t)npx * 2, hipMemcpyDeviceToDevice, st));
     if (e->params.speckleWindowSize > 0) {
-        const int newVal = (e->params.minDisparity - 1) * 16;
-        const int maxDiff = 16 * e->params.speckleRange;
-        int *label = (int *)e->label.p, *csz = (int *)e->csize.p;
-        dim3 g2((W + 255) / 256, H);
-        hipLaunchKernelGGL(k_ccl_init, dim3(nb_px), dim3(256), 0, st, (const int16_t *)d_disp, label, csz, npx, newVal);
-        hipLaunchKernelGGL(k_ccl_merge, g2, dim3(256), 0, st, (const int16_t *)d_disp, label, H, W, newVal, maxDiff);
-        hipLaunchKernelGGL(k_ccl_count, dim3(nb_px), dim3(256), 0, st, label, csz, npx);
-        hipLaunchKernelGGL(k_ccl_apply, dim3(nb_px), dim3(256), 0, st, d_disp, (const int *)label, (const int *)csz, npx, newVal, e->params.speckleWindowSize);
-        KCHECK();
+        if ((rc = run_speckles(e, d_disp, H, W, (e->params.minDisparity - 1) * 16, e->params.speckleWindowSize,
+                               16 * e->params.speckleRange)))
+            return rc;
         nl = 5;
     }
     if ((rc = stage_end(e, nl))) return rc;
@@ -454,7 +462,7 @@ void sgm_destroy(sgm_engine *e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta,
-                      &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->f32, &e->xyz, &e->mask,
+                      &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
                       &e->minkey};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
@@ -618,6 +626,36 @@ int sgm_valid_mask(sgm_engine *e, const float *xyz, const float *disp, int64_t n
     HIP_TRY(hipMemcpyAsync(e->xyz.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
     if ((rc = sgm_valid_mask_device(e, e->xyz.p, e->f32.p, n, e->mask.p))) return rc;
     HIP_TRY(hipMemcpyAsync(mask, e->mask.p, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_median3x3(sgm_engine *e, const int16_t *src, int H, int W, int16_t *dst)
+{
+    if (!e || !src || !dst || H <= 0 || W <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t npx = (size_t)H * W;
+    int rc;
+    if ((rc = e->disp_raw.ensure(npx * 2)) || (rc = e->disp_med.ensure(npx * 2))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->disp_raw.p, src, npx * 2, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_median3, dim3((W + 255) / 256, H), dim3(256), 0, e->stream, (const int16_t *)e->disp_raw.p,
+                       (int16_t *)e->disp_med.p, H, W);
+    KCHECK();
+    HIP_TRY(hipMemcpyAsync(dst, e->disp_med.p, npx * 2, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_filter_speckles(sgm_engine *e, int16_t *img, int H, int W, int newVal, int maxSpeckleSize, int maxDiff)
+{
+    if (!e || !img || H <= 0 || W <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t npx = (size_t)H * W;
+    int rc;
+    if ((rc = e->disp_out.ensure(npx * 2))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->disp_out.p, img, npx * 2, hipMemcpyHostToDevice, e->stream));
+    if ((rc = run_speckles(e, (int16_t *)e->disp_out.p, H, W, newVal, maxSpeckleSize, maxDiff))) return rc;
+    HIP_TRY(hipMemcpyAsync(img, e->disp_out.p, npx * 2, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return SGM_OK;
 }

@@ -34,6 +34,9 @@ class error(Exception):
 _PARAM_NAMES = ("minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff",
                 "preFilterCap", "uniquenessRatio", "speckleWindowSize", "speckleRange", "mode")
 
+_DEFAULT = dict(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0, preFilterCap=0,
+                uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=0)
+
 _device = None
 
 
@@ -59,6 +62,10 @@ class Engine:
 
     def __init__(self, params: dict, device: int | None = None, stream: int | None = None):
         self._L = _lib.load()
+        params = {**_DEFAULT, **params}     # cv2.StereoSGBM_create defaults for missing keys
+        unknown = set(params) - set(_PARAM_NAMES)
+        if unknown:
+            raise TypeError(f"unknown StereoSGBM parameter(s): {sorted(unknown)}")
         self.params = dict(params)
         self.device = get_device() if device is None else int(device)
         p = _lib.SgmParams(*[int(params[n]) for n in _PARAM_NAMES])
@@ -136,6 +143,18 @@ class Engine:
                                      out.ctypes.data))
         return out
 
+    def median3x3_host(self, img: np.ndarray) -> np.ndarray:
+        img = np.ascontiguousarray(img, np.int16)
+        out = np.empty_like(img)
+        _check(self._L.sgm_median3x3(self._h, img.ctypes.data, img.shape[0], img.shape[1], out.ctypes.data))
+        return out
+
+    def filter_speckles_host(self, img: np.ndarray, newVal: int, maxSpeckleSize: int, maxDiff: int) -> np.ndarray:
+        out = np.array(img, dtype=np.int16, order="C", copy=True)
+        _check(self._L.sgm_filter_speckles(self._h, out.ctypes.data, out.shape[0], out.shape[1], int(newVal),
+                                           int(maxSpeckleSize), int(maxDiff)))
+        return out
+
     def valid_mask_host(self, xyz: np.ndarray, disp: np.ndarray) -> np.ndarray:
         xyz = np.ascontiguousarray(xyz, np.float32)
         disp = np.ascontiguousarray(disp, np.float32)
@@ -174,6 +193,7 @@ _CACHE_MAX = 4
 
 def get_engine(params: dict, device: int | None = None) -> Engine:
     dev = get_device() if device is None else int(device)
+    params = {**_DEFAULT, **params}
     key = (tuple(int(params[n]) for n in _PARAM_NAMES), dev)
     e = _engine_cache.get(key)
     if e is None:
@@ -270,8 +290,6 @@ def StereoSGBM_create(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0
                       speckleWindowSize=speckleWindowSize, speckleRange=speckleRange, mode=mode)
 
 
-_DEFAULT = dict(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0, preFilterCap=0,
-                uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=0)
 
 
 def reprojectImageTo3D(disparity, Q, _3dImage=None, handleMissingValues=False, ddepth=-1):

@@ -155,3 +155,67 @@ def test_torch_device_path_zero_copy():
     out = cv.StereoSGBM_create(**p).compute(tl, tr)
     assert out.is_cuda and out.dtype == torch.int16
     assert np.array_equal(out.cpu().numpy(), O.sgbm_compute(l, r, **p))
+
+
+def _speckle_maps():
+    rng = np.random.default_rng(11)
+    H, W = 97, 203
+    maps = {}
+    maps["noise"] = rng.integers(-16, 300, (H, W)).astype(np.int16)
+    smooth = (np.add.outer(np.arange(H), np.arange(W)) // 3).astype(np.int16)
+    smooth[rng.random((H, W)) < 0.05] = -16
+    maps["smooth_with_holes"] = smooth
+    # serpentine: one long thin component that unions many runs in both directions
+    serp = np.full((H, W), -16, np.int16)
+    for y in range(0, H, 2):
+        serp[y, :] = 100
+        if y + 1 < H:
+            serp[y + 1, (W - 1) if (y // 2) % 2 == 0 else 0] = 100
+    maps["serpentine"] = serp
+    # spiral-ish nested rectangles joined at one corner each
+    sp = np.full((H, W), -16, np.int16)
+    for k in range(0, min(H, W) // 2 - 1, 2):
+        sp[k, k:W - k] = 50; sp[H - 1 - k, k:W - k] = 50
+        sp[k:H - k, k] = 50; sp[k:H - k, W - 1 - k] = 50
+        if k + 2 < min(H, W) // 2 - 1:
+            sp[k + 1, k + 1] = 50
+    maps["rings"] = sp
+    # staircase of values: links depend on maxDiff exactly
+    maps["staircase"] = (np.arange(W)[None, :] * 7 + np.arange(H)[:, None] * 16).astype(np.int16)
+    blobs = np.full((H, W), -16, np.int16)
+    for _ in range(150):
+        y, x = rng.integers(0, H - 6), rng.integers(0, W - 6)
+        h, w = rng.integers(1, 6), rng.integers(1, 6)
+        blobs[y:y + h, x:x + w] = rng.integers(0, 500)
+    maps["blobs"] = blobs
+    maps["single_row"] = rng.integers(-16, 40, (1, 300)).astype(np.int16)
+    maps["single_col"] = rng.integers(-16, 40, (300, 1)).astype(np.int16)
+    return maps
+
+
+@pytest.mark.parametrize("name", sorted(_speckle_maps()))
+def test_speckle_filter_and_median_on_adversarial_maps(name):
+    import stereo_reconstruction_cv_amd as cv
+    img = _speckle_maps()[name]
+    eng = cv.get_engine(U.params(16, 3))
+    for maxSize, maxDiff in ((0, 0), (1, 0), (4, 7), (30, 16), (100, 512), (10 ** 6, 16)):
+        got = eng.filter_speckles_host(img, -16, maxSize, maxDiff)
+        want = O.filter_speckles(img, -16, maxSize, maxDiff)
+        assert np.array_equal(got, want), (name, maxSize, maxDiff, int((got != want).sum()))
+    assert np.array_equal(eng.median3x3_host(img), O.median3x3(img))
+
+
+def test_speckle_filter_large_frame():
+    """4K-sized map with huge smooth regions, thin bridges and salt noise (speckle stress)."""
+    import stereo_reconstruction_cv_amd as cv
+    rng = np.random.default_rng(3)
+    H, W = 1080, 1920
+    img = (np.add.outer(np.arange(H) // 7, np.arange(W) // 5) % 900).astype(np.int16)
+    img[rng.random((H, W)) < 0.02] = -16
+    img[::97, :] = -16
+    img[:, ::131] = -16
+    img[48::97, 65::131] = 5                     # bridges
+    eng = cv.get_engine(U.params(16, 3))
+    got = eng.filter_speckles_host(img, -16, 100, 16)
+    want = O.filter_speckles(img, -16, 100, 16)
+    assert np.array_equal(got, want)
