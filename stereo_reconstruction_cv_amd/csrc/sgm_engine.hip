@@ -17,6 +17,7 @@
 #include "kernels_cost.h"
 #include "kernels_path.h"
 #include "kernels_post.h"
+#include "kernels_sweep.h"
 
 using namespace sgm;
 
@@ -75,6 +76,8 @@ struct sgm_engine {
     bool own_stream = false;
     int keep_aggr = 0;
     int profile = 0;
+    int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps
+    int sweep_rows = 0;  // rows per band of the sweep (0 = automatic)
 
     // shape of the last compute
     int H = 0, W = 0;
@@ -84,6 +87,7 @@ struct sgm_engine {
     DevBuf lrec, rplanes;               // features
     DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
     DevBuf wta;                         // uint2 [H][W]
+    DevBuf bndL, bndM;                  // band-boundary state of the sweep pre-pass
     DevBuf disp_raw, disp_med, disp_out;  // int16 [H][W]
     DevBuf label, csize, rlen;          // int32 [H][W] each
     DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
@@ -159,32 +163,69 @@ static int stage_end(sgm_engine *e, int launches)
 // ---- path launch dispatch ---------------------------------------------------------------------
 template <int NP, bool PARTIAL>
 static void launch_path_np(const Geom &g, int rx, int ry, int mode, const int16_t *C, int16_t *S, int keepS,
-                           uint2 *wta, hipStream_t st)
+                           uint2 *wta, Boundary bd, hipStream_t st)
 {
     const int nlines = ry == 0 ? g.H : g.W1;
     dim3 grid(nlines), block(64);
     if (mode == PATH_FIRST)
-        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_FIRST>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta);
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_FIRST>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
     else if (mode == PATH_ACCUM)
-        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_ACCUM>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta);
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_ACCUM>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
+    else if (mode == PATH_LAST)
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_LAST>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
     else
-        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_LAST>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta);
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_BOUNDARY>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
 }
 
 static void launch_path(const Geom &g, int rx, int ry, int mode, const int16_t *C, int16_t *S, int keepS,
-                        uint2 *wta, hipStream_t st)
+                        uint2 *wta, hipStream_t st, Boundary bd = Boundary{nullptr, nullptr, 1, 0})
 {
     const bool partial = g.D != 128 * g.NP;
     if (g.NP == 1) {
-        if (partial) launch_path_np<1, true>(g, rx, ry, mode, C, S, keepS, wta, st);
-        else launch_path_np<1, false>(g, rx, ry, mode, C, S, keepS, wta, st);
+        if (partial) launch_path_np<1, true>(g, rx, ry, mode, C, S, keepS, wta, bd, st);
+        else launch_path_np<1, false>(g, rx, ry, mode, C, S, keepS, wta, bd, st);
     } else if (g.NP == 2) {
-        if (partial) launch_path_np<2, true>(g, rx, ry, mode, C, S, keepS, wta, st);
-        else launch_path_np<2, false>(g, rx, ry, mode, C, S, keepS, wta, st);
+        if (partial) launch_path_np<2, true>(g, rx, ry, mode, C, S, keepS, wta, bd, st);
+        else launch_path_np<2, false>(g, rx, ry, mode, C, S, keepS, wta, bd, st);
     } else {
-        if (partial) launch_path_np<4, true>(g, rx, ry, mode, C, S, keepS, wta, st);
-        else launch_path_np<4, false>(g, rx, ry, mode, C, S, keepS, wta, st);
+        if (partial) launch_path_np<4, true>(g, rx, ry, mode, C, S, keepS, wta, bd, st);
+        else launch_path_np<4, false>(g, rx, ry, mode, C, S, keepS, wta, bd, st);
     }
+}
+
+// ---- sweep launch dispatch --------------------------------------------------------------------
+template <int NP, bool PARTIAL, int MODE>
+static int launch_sweep_one(const Geom &g, const SweepArgs &a, int nbands, hipStream_t st)
+{
+    const size_t lds = sweep_lds_bytes(NP, a.R);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<NP, PARTIAL, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_sweep<NP, PARTIAL, MODE>), dim3(nbands), dim3((a.R + 1) * 64), lds, st, g, a);
+    return SGM_OK;
+}
+template <int NP, bool PARTIAL>
+static int launch_sweep_np(const Geom &g, const SweepArgs &a, int mode, int nbands, hipStream_t st)
+{
+    if (mode == SWEEP_FIRST) return launch_sweep_one<NP, PARTIAL, SWEEP_FIRST>(g, a, nbands, st);
+    if (mode == SWEEP_ACCUM) return launch_sweep_one<NP, PARTIAL, SWEEP_ACCUM>(g, a, nbands, st);
+    return launch_sweep_one<NP, PARTIAL, SWEEP_LAST>(g, a, nbands, st);
+}
+static int launch_sweep(const Geom &g, const SweepArgs &a, int mode, int nbands, hipStream_t st)
+{
+    const bool partial = g.D != 128 * g.NP;
+    if (g.NP == 1) return partial ? launch_sweep_np<1, true>(g, a, mode, nbands, st) : launch_sweep_np<1, false>(g, a, mode, nbands, st);
+    if (g.NP == 2) return partial ? launch_sweep_np<2, true>(g, a, mode, nbands, st) : launch_sweep_np<2, false>(g, a, mode, nbands, st);
+    return partial ? launch_sweep_np<4, true>(g, a, mode, nbands, st) : launch_sweep_np<4, false>(g, a, mode, nbands, st);
+}
+
+// rows per band: about 240 bands (one workgroup per CU, most of the 256 CUs busy), bounded by
+// SWEEP_MAX_ROWS (register budget of the workgroup) and the 160 KiB of LDS
+static int sweep_rows_for(const Geom &g, int override_rows)
+{
+    int maxR = SWEEP_MAX_ROWS;
+    while (maxR > 1 && sweep_lds_bytes(g.NP, maxR) > 160 * 1024) maxR--;
+    int R = override_rows > 0 ? override_rows : (g.H + 239) / 240;
+    if (override_rows <= 0) R = std::max(R, 4);
+    return std::max(1, std::min(R, maxR));
 }
 
 // ---- the matcher on device buffers ---------------------------------------------------------
@@ -307,34 +348,70 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         }
         if ((rc = stage_end(e, 1))) return rc;
 
-        // -- path aggregation: vertical-ish first, horizontal last (the last one does WTA)
-        struct Dir { int rx, ry; const char *name; };
-        static const Dir down[3] = {{0, 1, "path_S"}, {1, 1, "path_SE"}, {-1, 1, "path_SW"}};
-        static const Dir upw[3] = {{0, -1, "path_N"}, {1, -1, "path_NE"}, {-1, -1, "path_NW"}};
-        bool first = true;
-        for (int k = 0; k < 3; k++) {
-            if ((rc = stage_begin(e, down[k].name))) return rc;
-            launch_path(g, down[k].rx, down[k].ry, first ? PATH_FIRST : PATH_ACCUM, C, S, 0, wta, st);
-            KCHECK();
-            first = false;
-            if ((rc = stage_end(e, 1))) return rc;
-        }
-        if (g.mode == 1) {
+        if (e->schedule == 0) {
+            // -- v1 schedule: one kernel per direction, vertical-ish first, horizontal last (WTA)
+            struct Dir { int rx, ry; const char *name; };
+            static const Dir down[3] = {{0, 1, "path_S"}, {1, 1, "path_SE"}, {-1, 1, "path_SW"}};
+            static const Dir upw[3] = {{0, -1, "path_N"}, {1, -1, "path_NE"}, {-1, -1, "path_NW"}};
+            bool first = true;
             for (int k = 0; k < 3; k++) {
-                if ((rc = stage_begin(e, upw[k].name))) return rc;
-                launch_path(g, upw[k].rx, upw[k].ry, PATH_ACCUM, C, S, 0, wta, st);
+                if ((rc = stage_begin(e, down[k].name))) return rc;
+                launch_path(g, down[k].rx, down[k].ry, first ? PATH_FIRST : PATH_ACCUM, C, S, 0, wta, st);
+                KCHECK();
+                first = false;
+                if ((rc = stage_end(e, 1))) return rc;
+            }
+            if (g.mode == 1) {
+                for (int k = 0; k < 3; k++) {
+                    if ((rc = stage_begin(e, upw[k].name))) return rc;
+                    launch_path(g, upw[k].rx, upw[k].ry, PATH_ACCUM, C, S, 0, wta, st);
+                    KCHECK();
+                    if ((rc = stage_end(e, 1))) return rc;
+                }
+            }
+            if ((rc = stage_begin(e, "path_E"))) return rc;
+            launch_path(g, 1, 0, PATH_ACCUM, C, S, 0, wta, st);
+            KCHECK();
+            if ((rc = stage_end(e, 1))) return rc;
+            if ((rc = stage_begin(e, "path_W_wta"))) return rc;
+            launch_path(g, -1, 0, PATH_LAST, C, S, e->keep_aggr, wta, st);
+            KCHECK();
+            if ((rc = stage_end(e, 1))) return rc;
+        } else {
+            // -- fused schedule: per pass a read-only boundary pre-pass (3 line scans) + one sweep
+            const int R = sweep_rows_for(g, e->sweep_rows);
+            const int nbands = (H + R - 1) / R;
+            if (nbands > 1) {
+                if ((rc = e->bndL.ensure((size_t)nbands * g.W1 * 3 * g.D * 2))) return rc;
+                if ((rc = e->bndM.ensure((size_t)nbands * g.W1 * 16))) return rc;
+            }
+            const int npass = g.mode == 1 ? 2 : 1;
+            for (int pass = 0; pass < npass; pass++) {
+                const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
+                if (nbands > 1) {
+                    if ((rc = stage_begin(e, pass == 0 ? "prepass_dn" : "prepass_up"))) return rc;
+                    static const int rxs[3] = {1, 0, -1};
+                    for (int k = 0; k < 3; k++) {
+                        Boundary bd{(int16_t *)e->bndL.p, (int32_t *)e->bndM.p, R, k};
+                        launch_path(g, rxs[k], ydir, PATH_BOUNDARY, C, S, 0, wta, st, bd);
+                    }
+                    KCHECK();
+                    if ((rc = stage_end(e, 3))) return rc;
+                }
+                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)e->bndL.p, (const int32_t *)e->bndM.p, wta, e->keep_aggr};
+                const bool last = pass == npass - 1 && g.mode == 1;
+                if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : "sweep_up_wta"))) return rc;
+                if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) return rc;
+                KCHECK();
+                if ((rc = stage_end(e, 1))) return rc;
+            }
+            if (g.mode == 0) {
+                if ((rc = stage_begin(e, "path_W_wta"))) return rc;
+                launch_path(g, -1, 0, PATH_LAST, C, S, e->keep_aggr, wta, st);
                 KCHECK();
                 if ((rc = stage_end(e, 1))) return rc;
             }
         }
-        if ((rc = stage_begin(e, "path_E"))) return rc;
-        launch_path(g, 1, 0, PATH_ACCUM, C, S, 0, wta, st);
-        KCHECK();
-        if ((rc = stage_end(e, 1))) return rc;
-        if ((rc = stage_begin(e, "path_W_wta"))) return rc;
-        launch_path(g, -1, 0, PATH_LAST, C, S, e->keep_aggr, wta, st);
-        KCHECK();
-        if ((rc = stage_end(e, 1))) return rc;
 
         // -- right view, sub-pixel, LR check
         if ((rc = stage_begin(e, "select_lr"))) return rc;
@@ -461,7 +538,7 @@ void sgm_destroy(sgm_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta,
+    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta, &e->bndL, &e->bndM,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
                       &e->minkey};
     for (DevBuf *b : bufs) b->release();
@@ -475,6 +552,8 @@ int sgm_set_option(sgm_engine *e, int option, int value)
     if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
     if (option == SGM_OPT_KEEP_AGGR) e->keep_aggr = value ? 1 : 0;
     else if (option == SGM_OPT_PROFILE) e->profile = value ? 1 : 0;
+    else if (option == SGM_OPT_SCHEDULE) e->schedule = value ? 1 : 0;
+    else if (option == SGM_OPT_SWEEP_ROWS) e->sweep_rows = std::max(0, value);
     else return set_err(SGM_ERR_INVALID_ARG, "unknown option %d", option);
     return SGM_OK;
 }

@@ -17,9 +17,11 @@ def params(D, bs, minD=0, mode=0, **kw):
     return p
 
 
-def run_hip_with_taps(left, right, p):
+def run_hip_with_taps(left, right, p, schedule=1, sweep_rows=0):
     eng = Engine(p)
     eng.set_option(_lib.SGM_OPT_KEEP_AGGR, 1)
+    eng.set_option(_lib.SGM_OPT_SCHEDULE, schedule)
+    eng.set_option(_lib.SGM_OPT_SWEEP_ROWS, sweep_rows)
     H, W = left.shape
     disp = eng.compute_host(left, right)
     _, W1 = eng.geometry(W)
@@ -31,11 +33,11 @@ def run_hip_with_taps(left, right, p):
     return out
 
 
-def compare_stages(left, right, p):
+def compare_stages(left, right, p, schedule=1, sweep_rows=0):
     """Returns (report dict stage -> mismatch count, oracle taps)."""
     d, t = O.sgbm_compute(left, right, taps=True, **p)
     t["disp"] = d
-    h = run_hip_with_taps(left, right, p)
+    h = run_hip_with_taps(left, right, p, schedule, sweep_rows)
     rep = {}
     for k in ("C", "S", "disp_raw", "disp_median", "disp"):
         if k in h and k in t:

@@ -35,12 +35,35 @@ CASES = [
 
 @pytest.mark.parametrize("H,W,D,bs,minD,mode,seed", CASES)
 def test_every_stage_bit_exact(H, W, D, bs, minD, mode, seed):
+    """default schedule: fused 4-direction sweeps (k_sweep) + boundary pre-pass"""
     l, r, _ = synth.make_pair(H, W, D, seed)
     p = U.params(D, bs, minD, mode, speckleWindowSize=30, speckleRange=2)
     rep, t, h = U.compare_stages(l, r, p)
     assert t["headroom_ok"]
     bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("H,W,D,bs,minD,mode,seed", CASES[::2])
+def test_every_stage_bit_exact_per_direction_schedule(H, W, D, bs, minD, mode, seed):
+    """schedule 0: one k_path launch per direction"""
+    l, r, _ = synth.make_pair(H, W, D, seed)
+    p = U.params(D, bs, minD, mode, speckleWindowSize=30, speckleRange=2)
+    rep, t, h = U.compare_stages(l, r, p, schedule=0)
+    bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 9])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sweep_band_heights(rows, mode):
+    """band height of the fused sweep must not matter (boundary pre-pass + LDS hand-off)"""
+    for (H, W, D, bs, seed) in ((37, 300, 64, 5, 61), (23, 420, 256, 7, 62), (19, 260, 48, 3, 63)):
+        l, r, _ = synth.make_pair(H, W, D, seed)
+        p = U.params(D, bs, 0, mode, speckleWindowSize=30, speckleRange=2)
+        rep, t, h = U.compare_stages(l, r, p, schedule=1, sweep_rows=rows)
+        bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
+        assert not bad, f"rows={rows} {(H, W, D)}: " + "\n".join(bad)
 
 
 def test_more_columns_than_disparities_required():
