@@ -23,16 +23,20 @@ namespace sgm {
 
 enum { PATH_FIRST = 0, PATH_ACCUM = 1, PATH_LAST = 2, PATH_BOUNDARY = 3 };
 
-// One step of the recurrence for the D disparities a wavefront holds.  Lq / mq: predecessor
-// state (idle lanes of a partial wave hold the MAX_COST sentinel); returns L(p, .) and its min.
+// One step of the recurrence for the D disparities a wavefront holds, on NORMALISED state:
+// the wave carries Lq'(d) = L_r(q,d) - min_k L_r(q,k), for which the recurrence reads
+//     L_r(p,d) = C(p,d) + min(Lq'(d), Lq'(d-1)+P1, Lq'(d+1)+P1, P2)
+// (no minimum needed inside the element-wise part).  Returns the un-normalised L_r(p,.), which
+// is what S accumulates, and the per-lane partial minimum (both int16 halves) for the caller to
+// reduce -- alone (wave_min_pk) or batched with other directions.  Idle lanes of a partial wave
+// hold the MAX_COST sentinel.
 template <int NP, bool PARTIAL>
-__device__ __forceinline__ void path_recur(const Pack<NP> &Cp, const Pack<NP> &Lq, uint32_t mq, uint32_t P1s,
-                                           uint32_t P2, bool active, Pack<NP> &Ln, uint32_t &mn)
+__device__ __forceinline__ void path_elem(const Pack<NP> &Cp, const Pack<NP> &Lq, uint32_t P1s, uint32_t P2s,
+                                          bool active, Pack<NP> &Ln, uint32_t &rmin)
 {
     const uint32_t up = from_lower_lane(Lq.r[NP - 1], SGM_SENT);
     const uint32_t dn = from_upper_lane(Lq.r[0], SGM_SENT);
-    const uint32_t mP2s = splat16(mq + P2), ms = splat16(mq);
-    uint32_t rmin = SGM_SENT;
+    rmin = SGM_SENT;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const uint32_t prevp = i == 0 ? up : Lq.r[i - 1];
@@ -40,13 +44,25 @@ __device__ __forceinline__ void path_recur(const Pack<NP> &Cp, const Pack<NP> &L
         const uint32_t lm1 = __builtin_amdgcn_alignbit(Lq.r[i], prevp, 16);
         const uint32_t lp1 = __builtin_amdgcn_alignbit(nextp, Lq.r[i], 16);
         uint32_t t = pk_adds_s(pk_min_s(lm1, lp1), P1s);
-        t = pk_min_s(pk_min_s(t, Lq.r[i]), mP2s);
-        uint32_t v = pk_add(Cp.r[i], pk_sub(t, ms));
+        t = pk_min_s(pk_min_s(t, Lq.r[i]), P2s);
+        uint32_t v = pk_add(Cp.r[i], t);
         if (PARTIAL) v = active ? v : SGM_SENT;
         Ln.r[i] = v;
         rmin = pk_min_s(rmin, v);
     }
-    mn = wave_min_u32(min(rmin & 0xffffu, rmin >> 16));
+}
+
+// Ln - m on active lanes (m: wave-uniform minimum); idle lanes keep the sentinel
+template <int NP, bool PARTIAL>
+__device__ __forceinline__ void path_normalise(const Pack<NP> &Ln, uint32_t m, bool active, Pack<NP> &out)
+{
+    const uint32_t ms = splat16(m);
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        uint32_t v = pk_sub(Ln.r[i], ms);
+        if (PARTIAL) v = active ? v : SGM_SENT;
+        out.r[i] = v;
+    }
 }
 
 // Winner-take-all on the finished S of one pixel (A.6 steps 1-2; steps 3-4 run in k_select):
@@ -94,16 +110,17 @@ __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool ac
 
 struct Cursor {
     int xi, y;
+    int64_t off;  // element offset of pixel (xi, y) in a [H][W1][D] volume, kept incrementally
 };
 
 // Band-boundary state written by the PATH_BOUNDARY pre-pass and read by k_sweep:
-//   bnd [band][x][3][D] int16 : L of directions (x-1), (x), (x+1) of the previous row
-//   bmin[band][x][4]    int32 : their minima
+//   bnd [band][x][3][D] int16 : normalised L of the three directions that come from the
+//   previous row, slot 0: predecessor one step EARLIER in the sweep's x order, 1: same column,
+//   2: one step LATER
 struct Boundary {
     int16_t *L;
-    int32_t *M;
     int R;       // rows per band
-    int slot;    // which of the three directions this launch writes (0: rx=+1, 1: rx=0, 2: rx=-1)
+    int slot;    // which of the three slots this launch writes
 };
 
 template <int NP, bool PARTIAL, int MODE>
@@ -118,7 +135,7 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
     const int nsteps = ry == 0 ? W1 : g.H;
     const bool active = !PARTIAL || (2 * NP * lane < D);
     const int lane_off = active ? 2 * NP * lane : 0;  // idle lanes load lane 0's data (ignored)
-    const uint32_t P1s = splat16((uint32_t)g.P1);
+    const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     const uint32_t init = active ? 0u : SGM_SENT;  // idle lanes act as the d = D sentinel
 
     Cursor ld, cp;  // load cursor runs ahead of the compute cursor
@@ -129,25 +146,32 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
         ld.y = ry > 0 ? 0 : g.H - 1;
         ld.xi = line;
     }
+    ld.off = ((int64_t)ld.y * W1 + ld.xi) * D;
     cp = ld;
+    const int64_t step_off = ((int64_t)ry * W1 + rx) * D, row_off = (int64_t)W1 * D;
 
     auto advance = [&](Cursor &c) -> bool {  // returns true when the predecessor left the domain
         c.xi += rx;
         c.y += ry;
+        c.off += step_off;
         if (c.xi >= W1) {
             c.xi = 0;
+            c.off -= row_off;
             return true;
         }
         if (c.xi < 0) {
             c.xi = W1 - 1;
+            c.off += row_off;
             return true;
         }
         return false;
     };
 
-    Pack<NP> L;
+    // PATH_BOUNDARY: rows until the next band boundary, and the band that boundary feeds
+    int to_boundary = bd.R - 1, next_band = 1;
+
+    Pack<NP> L;  // normalised state L_r(q,.) - min (all-zero when q is outside the domain)
     L.fill(init);
-    uint32_t m = 0;
 
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
     constexpr bool READS_S = (MODE == PATH_ACCUM || MODE == PATH_LAST);
@@ -156,9 +180,8 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
 #pragma unroll
         for (int k = 0; k < PB; k++) {
             if (step0 + k < nsteps) {
-                const int64_t off = ((int64_t)ld.y * W1 + ld.xi) * D + lane_off;
-                cb[k].load(C + off);
-                if (READS_S) sb[k].load(S + off);
+                cb[k].load(C + ld.off + lane_off);
+                if (READS_S) sb[k].load(S + ld.off + lane_off);
                 advance(ld);
             }
         }
@@ -168,20 +191,22 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
 #pragma unroll
         for (int k = 0; k < PB; k++) {
             if (step0 + k < nsteps) {
-                Pack<NP> Ln;
-                uint32_t m_new;
-                path_recur<NP, PARTIAL>(cb[k], L, m, P1s, (uint32_t)g.P2, active, Ln, m_new);
+                Pack<NP> Ln, Lnorm;
+                uint32_t rmin;
+                path_elem<NP, PARTIAL>(cb[k], L, P1s, P2s, active, Ln, rmin);
+                path_normalise<NP, PARTIAL>(Ln, halves_min(wave_min_pk(rmin)), active, Lnorm);
 
                 if (MODE == PATH_BOUNDARY) {
                     // state of the last row of a band, consumed by the first row of the next band
-                    const int j = ry > 0 ? cp.y : g.H - 1 - cp.y;  // row index in sweep order
-                    if ((j + 1) % bd.R == 0 && j + 1 < g.H) {
-                        const int64_t px = (int64_t)((j + 1) / bd.R) * W1 + cp.xi;
-                        if (active) Ln.store(bd.L + (px * 3 + bd.slot) * D + lane_off);
-                        if (lane == 0) bd.M[px * 4 + bd.slot] = (int32_t)m_new;
+                    if (to_boundary == 0) {
+                        const int64_t px = (int64_t)next_band * W1 + cp.xi;
+                        if (active && step0 + k + 1 < nsteps) Lnorm.store(bd.L + (px * 3 + bd.slot) * D + lane_off);
+                        to_boundary = bd.R;
+                        next_band++;
                     }
+                    to_boundary--;
                 } else {
-                    const int64_t off = ((int64_t)cp.y * W1 + cp.xi) * D + lane_off;
+                    const int64_t off = cp.off + lane_off;
                     Pack<NP> Sn;
 #pragma unroll
                     for (int i = 0; i < NP; i++)
@@ -195,12 +220,8 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
                     }
                 }
 
-                L = Ln;
-                m = m_new;
-                if (advance(cp)) {
-                    L.fill(init);
-                    m = 0;
-                }
+                L = Lnorm;
+                if (advance(cp)) L.fill(init);
             }
         }
     };

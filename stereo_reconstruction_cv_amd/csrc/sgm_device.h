@@ -51,16 +51,45 @@ __device__ __forceinline__ uint32_t from_upper_lane(uint32_t v, uint32_t fill)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, DPP_WAVE_SHL1, 0xf, 0xf, false);
 }
 
-// min over the 64 lanes of an unsigned 32-bit value; result is wave-uniform (SGPR)
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+// One butterfly / broadcast step of a wave-wide reduction: y = x as seen through a DPP control.
+// mov_dpp (no "old" operand) lets the compiler emit a single v_mov_b32_dpp without a copy.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_view(uint32_t x)
 {
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_QUAD_1032, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_QUAD_2301, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_MIRROR, 0xf, 0xf, false));
-    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return min(min(a, b), min(c, d));
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, CTRL, ROW_MASK, 0xf, true);
+}
+enum : int { DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143 };
+
+// min over the 64 lanes of both int16 halves of x at once; the wave-uniform result packs
+// {min of low halves, min of high halves}.  4 butterfly steps inside each row of 16 lanes, then
+// row_bcast 15 / 31 fold the rows into lane 63 (rows masked off in those two steps hold
+// garbage afterwards -- only lane 63 is read).
+__device__ __forceinline__ uint32_t wave_min_pk(uint32_t x)
+{
+    x = pk_min_s(x, dpp_view<DPP_QUAD_1032>(x));
+    x = pk_min_s(x, dpp_view<DPP_QUAD_2301>(x));
+    x = pk_min_s(x, dpp_view<DPP_ROW_HALF_MIRROR>(x));
+    x = pk_min_s(x, dpp_view<DPP_ROW_MIRROR>(x));
+    x = pk_min_s(x, dpp_view<DPP_ROW_BCAST15, 0xa>(x));
+    x = pk_min_s(x, dpp_view<DPP_ROW_BCAST31, 0xc>(x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+// min of the two halves of a wave-uniform packed pair
+__device__ __forceinline__ uint32_t halves_min(uint32_t pk) { return min(pk & 0xffffu, pk >> 16); }
+// {a.lo, b.lo} and {a.hi, b.hi}
+__device__ __forceinline__ uint32_t pack_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// min over the 64 lanes of an unsigned 32-bit value; result is wave-uniform (SGPR)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
+{
+    x = min(x, dpp_view<DPP_QUAD_1032>(x));
+    x = min(x, dpp_view<DPP_QUAD_2301>(x));
+    x = min(x, dpp_view<DPP_ROW_HALF_MIRROR>(x));
+    x = min(x, dpp_view<DPP_ROW_MIRROR>(x));
+    x = min(x, dpp_view<DPP_ROW_BCAST15, 0xa>(x));
+    x = min(x, dpp_view<DPP_ROW_BCAST31, 0xc>(x));
+    return __builtin_amdgcn_readlane(x, 63);
 }
 
 // NP packed registers per lane, moved as one vector access

@@ -87,7 +87,7 @@ struct sgm_engine {
     DevBuf lrec, rplanes;               // features
     DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
     DevBuf wta;                         // uint2 [H][W]
-    DevBuf bndL, bndM;                  // band-boundary state of the sweep pre-pass
+    DevBuf bndL;                        // band-boundary state of the sweep pre-pass
     DevBuf disp_raw, disp_med, disp_out;  // int16 [H][W]
     DevBuf label, csize, rlen;          // int32 [H][W] each
     DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
@@ -178,7 +178,7 @@ static void launch_path_np(const Geom &g, int rx, int ry, int mode, const int16_
 }
 
 static void launch_path(const Geom &g, int rx, int ry, int mode, const int16_t *C, int16_t *S, int keepS,
-                        uint2 *wta, hipStream_t st, Boundary bd = Boundary{nullptr, nullptr, 1, 0})
+                        uint2 *wta, hipStream_t st, Boundary bd = Boundary{nullptr, 1, 0})
 {
     const bool partial = g.D != 128 * g.NP;
     if (g.NP == 1) {
@@ -383,22 +383,23 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             const int nbands = (H + R - 1) / R;
             if (nbands > 1) {
                 if ((rc = e->bndL.ensure((size_t)nbands * g.W1 * 3 * g.D * 2))) return rc;
-                if ((rc = e->bndM.ensure((size_t)nbands * g.W1 * 16))) return rc;
             }
             const int npass = g.mode == 1 ? 2 : 1;
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
                 if (nbands > 1) {
                     if ((rc = stage_begin(e, pass == 0 ? "prepass_dn" : "prepass_up"))) return rc;
-                    static const int rxs[3] = {1, 0, -1};
+                    // role 0: predecessor one step earlier in the sweep's x order (x - xdir), 1: same
+                    // column, 2: one step later
+                    const int rxs[3] = {xdir, 0, -xdir};
                     for (int k = 0; k < 3; k++) {
-                        Boundary bd{(int16_t *)e->bndL.p, (int32_t *)e->bndM.p, R, k};
+                        Boundary bd{(int16_t *)e->bndL.p, R, k};
                         launch_path(g, rxs[k], ydir, PATH_BOUNDARY, C, S, 0, wta, st, bd);
                     }
                     KCHECK();
                     if ((rc = stage_end(e, 3))) return rc;
                 }
-                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)e->bndL.p, (const int32_t *)e->bndM.p, wta, e->keep_aggr};
+                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)e->bndL.p, wta, e->keep_aggr};
                 const bool last = pass == npass - 1 && g.mode == 1;
                 if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : "sweep_up_wta"))) return rc;
                 if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) return rc;
@@ -538,7 +539,7 @@ void sgm_destroy(sgm_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta, &e->bndL, &e->bndM,
+    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta, &e->bndL,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
                       &e->minkey};
     for (DevBuf *b : bufs) b->release();
