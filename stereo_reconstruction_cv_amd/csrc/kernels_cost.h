@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
         const uint2 rec = lds_lrec[j - j0];
         const uint32_t U = splat16(rec.x & 0xff), U0 = splat16((rec.x >> 8) & 0xff), U1 = splat16((rec.x >> 16) & 0xff);
         const uint32_t R = splat16(rec.y & 0xff), R0 = splat16((rec.y >> 8) & 0xff), R1 = splat16((rec.y >> 16) & 0xff);
-        uint32_t *slot = ring + ((j % RS) * 64 + lane) * NP;
+        uint32_t *slot = ring + ((j & (RS - 1)) * 64 + lane) * NP;
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             uint32_t a = bt_pair(U, U0, U1, w[0][i], w[1][i], w[2][i]);
@@ -188,13 +188,13 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
                 for (int i = 0; i < NP; i++) hs[i] = 0;
                 for (int t = -SW2; t <= SW2; t++) {
                     const int jc = min(max(x + t, 0), W1 - 1);
-                    const uint32_t *p = ring + ((jc % RS) * 64 + lane) * NP;
+                    const uint32_t *p = ring + ((jc & (RS - 1)) * 64 + lane) * NP;
 #pragma unroll
                     for (int i = 0; i < NP; i++) hs[i] = pk_add(hs[i], p[i]);
                 }
             } else {
-                const uint32_t *pa = ring + ((min(x + SW2, W1 - 1) % RS) * 64 + lane) * NP;
-                const uint32_t *pb = ring + ((max(x - SW2 - 1, 0) % RS) * 64 + lane) * NP;
+                const uint32_t *pa = ring + ((min(x + SW2, W1 - 1) & (RS - 1)) * 64 + lane) * NP;
+                const uint32_t *pb = ring + ((max(x - SW2 - 1, 0) & (RS - 1)) * 64 + lane) * NP;
 #pragma unroll
                 for (int i = 0; i < NP; i++) hs[i] = pk_sub(pk_add(hs[i], pa[i]), pb[i]);
             }

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
                                              int16_t *__restrict__ S, int keepS,
                                              uint2 *__restrict__ wta, Boundary bd)
 {
-    constexpr int PB = 8;  // steps per prefetch block
+    // steps per prefetch block (two blocks in flight); deeper where registers allow
+    constexpr int PB = (MODE == PATH_BOUNDARY || MODE == PATH_FIRST) ? (NP == 4 ? 8 : 16) : 8;
     const int lane = threadIdx.x;
     const int line = blockIdx.x;
     const int W1 = g.W1, D = g.D;
@@ -177,9 +178,10 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
     constexpr bool READS_S = (MODE == PATH_ACCUM || MODE == PATH_LAST);
 
     auto load_block = [&](Pack<NP> *cb, Pack<NP> *sb, int step0) {
+        const bool full = step0 + PB <= nsteps;  // all but the last block: no per-step guard
 #pragma unroll
         for (int k = 0; k < PB; k++) {
-            if (step0 + k < nsteps) {
+            if (full || step0 + k < nsteps) {
                 cb[k].load(C + ld.off + lane_off);
                 if (READS_S) sb[k].load(S + ld.off + lane_off);
                 advance(ld);
@@ -188,9 +190,10 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
     };
 
     auto compute_block = [&](Pack<NP> *cb, Pack<NP> *sb, int step0) {
+        const bool full = step0 + PB <= nsteps;
 #pragma unroll
         for (int k = 0; k < PB; k++) {
-            if (step0 + k < nsteps) {
+            if (full || step0 + k < nsteps) {
                 Pack<NP> Ln, Lnorm;
                 uint32_t rmin;
                 path_elem<NP, PARTIAL>(cb[k], L, P1s, P2s, active, Ln, rmin);

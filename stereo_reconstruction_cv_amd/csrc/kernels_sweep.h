@@ -8,12 +8,12 @@
 //
 // Schedule.  The image is cut into bands of R rows (in sweep order).  One workgroup owns one
 // band: R compute waves (one image row each) + 1 loader wave.  The compute waves run the row
-// recurrence in lockstep, wave r two pixels behind wave r-1, one workgroup barrier per pixel
-// step: the (normalised) state a row needs from the row above -- three L vectors per pixel --
-// travels through a 4-pixel LDS ring per wave and never touches HBM.  Bands do not wait for each
+// recurrence in lockstep, wave r two steps behind wave r-1, one workgroup barrier per step (a
+// step is two pixels for D <= 256): the (normalised) state a row needs from the row above -- three L vectors per pixel --
+// travels through a small LDS ring per wave and never touches HBM.  Bands do not wait for each
 // other: the state of the row above a band comes from the PATH_BOUNDARY pre-pass of k_path
 // (three read-only line scans that store L only at band boundaries); the loader wave prefetches
-// it from HBM into registers and feeds a 4-pixel LDS ring two pixels ahead of wave 0.
+// it from HBM into registers and feeds an LDS ring two steps ahead of wave 0.
 //
 // Everything is expressed in the sweep's own pixel order k (x = k or W1-1-k): role A = path
 // whose predecessor is pixel k-1 of the row above, B = pixel k, C = pixel k+1; which image
@@ -35,13 +35,17 @@ struct SweepArgs {
     int keepS;
 };
 
-constexpr int SWEEP_RING = 4;      // pixels of hand-off state kept per producer
 constexpr int SWEEP_MAX_ROWS = 9;  // compute waves per workgroup (640 threads -> 168 VGPRs per lane)
+// pixels a wave advances per lockstep step (one barrier per step): two give the scheduler two
+// independent dependency chains per wave and halve the barrier / LDS round trips per pixel
+__host__ __device__ constexpr int sweep_pps(int NP) { return NP == 4 ? 1 : 2; }
+// pixels of hand-off state kept per producer: consumers run 2 steps behind their producer
+__host__ __device__ constexpr int sweep_ring(int NP) { return 4 * sweep_pps(NP); }
 
 __host__ __device__ constexpr int sweep_slot_dwords(int NP) { return 192 * NP; }
 static inline size_t sweep_lds_bytes(int NP, int R)
 {
-    return (size_t)(R + 1) * SWEEP_RING * sweep_slot_dwords(NP) * 4;
+    return (size_t)(R + 1) * sweep_ring(NP) * sweep_slot_dwords(NP) * 4;
 }
 
 __device__ __forceinline__ void wg_barrier()
@@ -69,7 +73,9 @@ template <int NP, bool PARTIAL, int MODE>
 __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, SweepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    constexpr int PB = NP == 4 ? 4 : 8;  // prefetch block (pixels); smaller for wide lanes to stay in registers
+    constexpr int PPS = sweep_pps(NP);
+    constexpr int RING = sweep_ring(NP);
+    constexpr int PB = RING;  // prefetch block (pixels) = ring depth, so slot(k) = k % PB is static
     constexpr int SLOT = sweep_slot_dwords(NP);
     constexpr int ROLE = 64 * NP;  // dwords per role inside a slot
     const int R = a.R;
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     const int lane = threadIdx.x & 63;
     const int band = blockIdx.x;
     const int W1 = g.W1, D = g.D, H = g.H;
-    const int T = W1 + 2 * (R - 1);  // lockstep steps
+    const int T = (W1 + PPS - 1) / PPS + 2 * (R - 1);  // lockstep steps
     const bool active = !PARTIAL || (2 * NP * lane < D);
     const int lane_off = active ? 2 * NP * lane : 0;
     const uint32_t init = active ? 0u : SGM_SENT;
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     uint32_t *const ring0 = lds + lane * NP;
 
     if (wave == R) {
-        // ============ loader wave: boundary state HBM -> registers -> LDS, 2 pixels ahead ========
+        // ==== loader wave: boundary state HBM -> registers -> LDS, 2 steps ahead of wave 0 ====
         const bool has_prev = band > 0;
         Pack<NP> bA[PB][3], bB[PB][3];
         auto xof = [&](int k) { return a.xdir > 0 ? k : W1 - 1 - k; };
@@ -100,8 +106,8 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
                 }
             }
         };
-        auto wb = [&](Pack<NP>(*b)[3], int u) {  // pixel k with k % PB == u, k & 3 == u & 3
-            uint32_t *slot = ring0 + (u & 3) * SLOT;
+        auto wb = [&](Pack<NP>(*b)[3], int u) {  // pixel k with k % PB == u
+            uint32_t *slot = ring0 + u * SLOT;
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 Pack<NP> v;
@@ -114,44 +120,35 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
                 lds_store<NP>(v, slot + d * ROLE);
             }
         };
-        lb(bA, 0);
-        lb(bB, PB);
-        wb(bA, 0);
-        wb(bA, 1);
-        wg_barrier();  // prologue barrier: pixels 0 and 1 are in place
-        int t = 0;     // step t writes pixel t + 2
-#pragma unroll
-        for (int u = 2; u < PB; u++) {
+        int t = 0;
+        auto step_group = [&](Pack<NP>(*b)[3], int u0, int kbase) {  // PPS pixels, then the step barrier
             if (t < T) {
-                if (u < W1) wb(bA, u);
+#pragma unroll
+                for (int p = 0; p < PPS; p++)
+                    if (kbase + u0 + p < W1) wb(b, u0 + p);
                 wg_barrier();
                 t++;
             }
-        }
+        };
+        lb(bA, 0);
+        lb(bB, PB);
+#pragma unroll
+        for (int p = 0; p < 2 * PPS; p++) wb(bA, p);
+        wg_barrier();  // prologue barrier: the first two steps' worth of pixels is in place
+#pragma unroll
+        for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) step_group(bA, u0, 0);
         for (int k0 = PB; t < T; k0 += 2 * PB) {
             lb(bA, k0 + PB);
 #pragma unroll
-            for (int u = 0; u < PB; u++) {
-                if (t < T) {
-                    if (k0 + u < W1) wb(bB, u);
-                    wg_barrier();
-                    t++;
-                }
-            }
+            for (int u0 = 0; u0 < PB; u0 += PPS) step_group(bB, u0, k0);
             lb(bB, k0 + 2 * PB);
 #pragma unroll
-            for (int u = 0; u < PB; u++) {
-                if (t < T) {
-                    if (k0 + PB + u < W1) wb(bA, u);
-                    wg_barrier();
-                    t++;
-                }
-            }
+            for (int u0 = 0; u0 < PB; u0 += PPS) step_group(bA, u0, k0 + PB);
         }
         return;
     }
 
-    // ============ compute wave: one image row =====================================================
+    // ==== compute wave: one image row ==============================================================
     const int j = band * R + wave;  // row index in sweep order
     const int y = a.ydir > 0 ? j : H - 1 - j;
     wg_barrier();  // prologue barrier
@@ -159,12 +156,12 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         for (int t = 0; t < T; t++) wg_barrier();
         return;
     }
-    const uint32_t *const prev = ring0 + wave * SWEEP_RING * SLOT;
-    uint32_t *const mine = ring0 + (wave + 1) * SWEEP_RING * SLOT;
+    const uint32_t *const prev = ring0 + wave * RING * SLOT;
+    uint32_t *const mine = ring0 + (wave + 1) * RING * SLOT;
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     constexpr bool READS_S = MODE != SWEEP_FIRST;
 
-    for (int i = 0; i < 2 * wave; i++) wg_barrier();  // start two pixels behind the row above
+    for (int i = 0; i < 2 * wave; i++) wg_barrier();  // start two steps behind the row above
 
     Pack<NP> L0;  // normalised state of the in-row path
     L0.fill(init);
@@ -188,53 +185,63 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         }
     };
 
-    auto compute_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {  // k0 is a multiple of PB
+    auto compute_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {  // k0 is a multiple of PB = RING
 #pragma unroll
-        for (int u = 0; u < PB; u++) {
-            const int k = k0 + u;
-            if (k < W1) {
-                // ---- normalised state of the row above (LDS); slot of pixel k is k & 3 = u & 3 ----
-                Pack<NP> QA, QB, QC;
-                QA.fill(init);
-                QC.fill(init);
-                if (k > 0) lds_load<NP>(QA, prev + ((u + 3) & 3) * SLOT + 0 * ROLE);
-                lds_load<NP>(QB, prev + (u & 3) * SLOT + 1 * ROLE);
-                if (k < W1 - 1) lds_load<NP>(QC, prev + ((u + 1) & 3) * SLOT + 2 * ROLE);
-                // ---- four recurrences, minima reduced two directions at a time ----
-                Pack<NP> N0, NA, NB, NC;
-                uint32_t r0, rA, rB, rC;
-                path_elem<NP, PARTIAL>(cb[u], L0, P1s, P2s, active, N0, r0);
-                path_elem<NP, PARTIAL>(cb[u], QA, P1s, P2s, active, NA, rA);
-                path_elem<NP, PARTIAL>(cb[u], QB, P1s, P2s, active, NB, rB);
-                path_elem<NP, PARTIAL>(cb[u], QC, P1s, P2s, active, NC, rC);
-                const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));  // {min 0, min A}
-                const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));  // {min B, min C}
-                Pack<NP> LA, LB, LC;
-                path_normalise<NP, PARTIAL>(N0, m0A & 0xffffu, active, L0);
-                path_normalise<NP, PARTIAL>(NA, m0A >> 16, active, LA);
-                path_normalise<NP, PARTIAL>(NB, mBC & 0xffffu, active, LB);
-                path_normalise<NP, PARTIAL>(NC, mBC >> 16, active, LC);
-                // ---- hand the three vertical states to the row below ----
-                {
-                    uint32_t *s = mine + (u & 3) * SLOT;
-                    lds_store<NP>(LA, s + 0 * ROLE);
-                    lds_store<NP>(LB, s + 1 * ROLE);
-                    lds_store<NP>(LC, s + 2 * ROLE);
-                }
-                // ---- S ----
-                Pack<NP> Sn;
+        for (int u0 = 0; u0 < PB; u0 += PPS) {
+            if (k0 + u0 < W1) {
+                // ---- normalised state of the row above for the PPS pixels of this step (LDS) ----
+                Pack<NP> QA[PPS], QB[PPS], QC[PPS];
 #pragma unroll
-                for (int i = 0; i < NP; i++) {
-                    uint32_t s = pk_adds_s(pk_adds_s(N0.r[i], NA.r[i]), pk_adds_s(NB.r[i], NC.r[i]));
-                    if (READS_S) s = pk_adds_s(s, sb[u].r[i]);
-                    Sn.r[i] = s;
+                for (int p = 0; p < PPS; p++) {
+                    const int u = u0 + p, k = k0 + u;
+                    QA[p].fill(init);
+                    QB[p].fill(init);
+                    QC[p].fill(init);
+                    if (k < W1) {
+                        if (k > 0) lds_load<NP>(QA[p], prev + ((u + RING - 1) % RING) * SLOT + 0 * ROLE);
+                        lds_load<NP>(QB[p], prev + u * SLOT + 1 * ROLE);
+                        if (k < W1 - 1) lds_load<NP>(QC[p], prev + ((u + 1) % RING) * SLOT + 2 * ROLE);
+                    }
                 }
-                if (MODE != SWEEP_LAST || a.keepS) {
-                    if (active) Sn.store(Srow + e0 + k * ek);
-                }
-                if (MODE == SWEEP_LAST) {
-                    const uint2 rec = wta_pixel<NP, PARTIAL>(Sn, lane, active, D, g.uniq);
-                    if (lane == 0) wrow[k * wk] = rec;
+#pragma unroll
+                for (int p = 0; p < PPS; p++) {
+                    const int u = u0 + p, k = k0 + u;
+                    if (k < W1) {
+                        // ---- four recurrences, minima reduced two directions at a time ----
+                        Pack<NP> N0, NA, NB, NC;
+                        uint32_t r0, rA, rB, rC;
+                        path_elem<NP, PARTIAL>(cb[u], L0, P1s, P2s, active, N0, r0);
+                        path_elem<NP, PARTIAL>(cb[u], QA[p], P1s, P2s, active, NA, rA);
+                        path_elem<NP, PARTIAL>(cb[u], QB[p], P1s, P2s, active, NB, rB);
+                        path_elem<NP, PARTIAL>(cb[u], QC[p], P1s, P2s, active, NC, rC);
+                        const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));  // {min 0, min A}
+                        const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));  // {min B, min C}
+                        Pack<NP> LA, LB, LC;
+                        path_normalise<NP, PARTIAL>(N0, m0A & 0xffffu, active, L0);
+                        path_normalise<NP, PARTIAL>(NA, m0A >> 16, active, LA);
+                        path_normalise<NP, PARTIAL>(NB, mBC & 0xffffu, active, LB);
+                        path_normalise<NP, PARTIAL>(NC, mBC >> 16, active, LC);
+                        // ---- hand the three vertical states to the row below ----
+                        uint32_t *s = mine + u * SLOT;
+                        lds_store<NP>(LA, s + 0 * ROLE);
+                        lds_store<NP>(LB, s + 1 * ROLE);
+                        lds_store<NP>(LC, s + 2 * ROLE);
+                        // ---- S ----
+                        Pack<NP> Sn;
+#pragma unroll
+                        for (int i = 0; i < NP; i++) {
+                            uint32_t v = pk_adds_s(pk_adds_s(N0.r[i], NA.r[i]), pk_adds_s(NB.r[i], NC.r[i]));
+                            if (READS_S) v = pk_adds_s(v, sb[u].r[i]);
+                            Sn.r[i] = v;
+                        }
+                        if (MODE != SWEEP_LAST || a.keepS) {
+                            if (active) Sn.store(Srow + e0 + k * ek);
+                        }
+                        if (MODE == SWEEP_LAST) {
+                            const uint2 rec = wta_pixel<NP, PARTIAL>(Sn, lane, active, D, g.uniq);
+                            if (lane == 0) wrow[k * wk] = rec;
+                        }
+                    }
                 }
                 wg_barrier();
             }

@@ -319,7 +319,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         {
             const int XL = 128;
             const int nchunks = (g.W1 + XL - 1) / XL;
-            const int RS = 2 * g.SW2 + 2;
+            int RS = 1;  // ring of the last blockSize+1 cost vectors, rounded to a power of two
+            while (RS < 2 * g.SW2 + 2) RS <<= 1;
             const HsumLds l = hsum_lds_layout(g.NP, RS, XL, g.SW2);
             dim3 grid((unsigned)((int64_t)H * nchunks)), block(64);
             const uint2 *lrec = (const uint2 *)e->lrec.p;
