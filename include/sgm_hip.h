@@ -77,7 +77,8 @@ typedef enum {
     SGM_OPT_KEEP_AGGR = 0,   /* 1: the last path kernel also stores S (debug; costs bandwidth)   */
     SGM_OPT_PROFILE = 1,     /* 1: bracket every stage with HIP events on the engine's stream    */
     SGM_OPT_SCHEDULE = 2,    /* 0: one kernel per path direction; 1 (default): fused 4-direction sweeps */
-    SGM_OPT_SWEEP_ROWS = 3   /* rows per band of the fused sweep; 0 = automatic                  */
+    SGM_OPT_SWEEP_ROWS = 3,  /* rows per band of the fused sweep; 0 = automatic                  */
+    SGM_OPT_DEBUG = 4        /* timing experiments only: non-zero values make results WRONG      */
 } sgm_option;
 
 #define SGM_MAX_STAGES 32

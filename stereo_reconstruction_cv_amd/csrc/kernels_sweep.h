@@ -90,6 +90,17 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     // ring 0 is fed by the loader (row above the band), ring r+1 by compute wave r
     uint32_t *const ring0 = lds + lane * NP;
 
+    // Out-of-image neighbours are ordinary ring slots holding the start state: "pixel -1" lives in
+    // slot RING-1 (written before the prologue barrier, not reused until pixel RING-1 exists) and
+    // "pixel W1" is written by each producer one step after its last real pixel.  The per-pixel
+    // code therefore needs no border branches.
+    auto write_start_state = [&](uint32_t *ring, int slot) {
+        Pack<NP> v;
+        v.fill(init);
+#pragma unroll
+        for (int d = 0; d < 3; d++) lds_store<NP>(v, ring + slot * SLOT + d * ROLE);
+    };
+
     if (wave == R) {
         // ==== loader wave: boundary state HBM -> registers -> LDS, 2 steps ahead of wave 0 ====
         const bool has_prev = band > 0;
@@ -106,16 +117,17 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
                 }
             }
         };
-        auto wb = [&](Pack<NP>(*b)[3], int u) {  // pixel k with k % PB == u
+        auto wb = [&](Pack<NP>(*b)[3], int u, int k) {  // pixel k, k % PB == u
+            if (k > W1) return;
             uint32_t *slot = ring0 + u * SLOT;
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 Pack<NP> v;
-                if (has_prev) {
+                if (has_prev && k < W1) {
                     v = b[u][d];
                     if (PARTIAL && !active) v.fill(SGM_SENT);
                 } else {
-                    v.fill(init);
+                    v.fill(init);  // first band of the sweep, or the virtual pixel W1
                 }
                 lds_store<NP>(v, slot + d * ROLE);
             }
@@ -124,16 +136,16 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         auto step_group = [&](Pack<NP>(*b)[3], int u0, int kbase) {  // PPS pixels, then the step barrier
             if (t < T) {
 #pragma unroll
-                for (int p = 0; p < PPS; p++)
-                    if (kbase + u0 + p < W1) wb(b, u0 + p);
+                for (int p = 0; p < PPS; p++) wb(b, u0 + p, kbase + u0 + p);
                 wg_barrier();
                 t++;
             }
         };
         lb(bA, 0);
         lb(bB, PB);
+        write_start_state(ring0, RING - 1);
 #pragma unroll
-        for (int p = 0; p < 2 * PPS; p++) wb(bA, p);
+        for (int p = 0; p < 2 * PPS; p++) wb(bA, p, p);
         wg_barrier();  // prologue barrier: the first two steps' worth of pixels is in place
 #pragma unroll
         for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) step_group(bA, u0, 0);
@@ -151,13 +163,14 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     // ==== compute wave: one image row ==============================================================
     const int j = band * R + wave;  // row index in sweep order
     const int y = a.ydir > 0 ? j : H - 1 - j;
+    const uint32_t *const prev = ring0 + wave * RING * SLOT;
+    uint32_t *const mine = ring0 + (wave + 1) * RING * SLOT;
+    write_start_state(mine, RING - 1);
     wg_barrier();  // prologue barrier
     if (j >= H) {  // row past the image (last band): keep the barrier count, do nothing
         for (int t = 0; t < T; t++) wg_barrier();
         return;
     }
-    const uint32_t *const prev = ring0 + wave * RING * SLOT;
-    uint32_t *const mine = ring0 + (wave + 1) * RING * SLOT;
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     constexpr bool READS_S = MODE != SWEEP_FIRST;
 
@@ -175,9 +188,10 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     uint2 *const wrow = a.wta + (int64_t)y * g.W + g.minX1 + (a.xdir > 0 ? 0 : W1 - 1);
 
     auto load_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {
+        const bool full = k0 + PB <= W1;
 #pragma unroll
         for (int u = 0; u < PB; u++) {
-            if (k0 + u < W1) {
+            if (full || k0 + u < W1) {
                 const int e = e0 + (k0 + u) * ek;
                 cb[u].load(Crow + e);
                 if (READS_S) sb[u].load(Srow + e);
@@ -185,63 +199,60 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         }
     };
 
+    // one pixel: four recurrences (minima reduced two directions at a time), hand-off, S, WTA
+    auto pixel = [&](const Pack<NP> &Cp, const Pack<NP> &Sp, const Pack<NP> &QA, const Pack<NP> &QB,
+                     const Pack<NP> &QC, int u, int k) {
+        Pack<NP> N0, NA, NB, NC;
+        uint32_t r0, rA, rB, rC;
+        path_elem<NP, PARTIAL>(Cp, L0, P1s, P2s, active, N0, r0);
+        path_elem<NP, PARTIAL>(Cp, QA, P1s, P2s, active, NA, rA);
+        path_elem<NP, PARTIAL>(Cp, QB, P1s, P2s, active, NB, rB);
+        path_elem<NP, PARTIAL>(Cp, QC, P1s, P2s, active, NC, rC);
+        const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));  // {min 0, min A}
+        const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));  // {min B, min C}
+        Pack<NP> LA, LB, LC;
+        path_normalise<NP, PARTIAL>(N0, m0A & 0xffffu, active, L0);
+        path_normalise<NP, PARTIAL>(NA, m0A >> 16, active, LA);
+        path_normalise<NP, PARTIAL>(NB, mBC & 0xffffu, active, LB);
+        path_normalise<NP, PARTIAL>(NC, mBC >> 16, active, LC);
+        uint32_t *s = mine + u * SLOT;
+        lds_store<NP>(LA, s + 0 * ROLE);
+        lds_store<NP>(LB, s + 1 * ROLE);
+        lds_store<NP>(LC, s + 2 * ROLE);
+        Pack<NP> Sn;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            uint32_t v = pk_adds_s(pk_adds_s(N0.r[i], NA.r[i]), pk_adds_s(NB.r[i], NC.r[i]));
+            if (READS_S) v = pk_adds_s(v, Sp.r[i]);
+            Sn.r[i] = v;
+        }
+        if (MODE != SWEEP_LAST || a.keepS) {
+            if (active) Sn.store(Srow + e0 + k * ek);
+        }
+        if (MODE == SWEEP_LAST) {
+            const uint2 rec = wta_pixel<NP, PARTIAL>(Sn, lane, active, D, g.uniq);
+            if (lane == 0) wrow[k * wk] = rec;
+        }
+    };
+
     auto compute_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {  // k0 is a multiple of PB = RING
+        const bool full = k0 + PB <= W1;  // all blocks but the last: straight-line code, no guards
 #pragma unroll
         for (int u0 = 0; u0 < PB; u0 += PPS) {
-            if (k0 + u0 < W1) {
-                // ---- normalised state of the row above for the PPS pixels of this step (LDS) ----
+            if (full || k0 + u0 < W1) {
+                // normalised state of the row above for the PPS pixels of this step (LDS)
                 Pack<NP> QA[PPS], QB[PPS], QC[PPS];
 #pragma unroll
                 for (int p = 0; p < PPS; p++) {
-                    const int u = u0 + p, k = k0 + u;
-                    QA[p].fill(init);
-                    QB[p].fill(init);
-                    QC[p].fill(init);
-                    if (k < W1) {
-                        if (k > 0) lds_load<NP>(QA[p], prev + ((u + RING - 1) % RING) * SLOT + 0 * ROLE);
-                        lds_load<NP>(QB[p], prev + u * SLOT + 1 * ROLE);
-                        if (k < W1 - 1) lds_load<NP>(QC[p], prev + ((u + 1) % RING) * SLOT + 2 * ROLE);
-                    }
+                    const int u = u0 + p;
+                    lds_load<NP>(QA[p], prev + ((u + RING - 1) % RING) * SLOT + 0 * ROLE);
+                    lds_load<NP>(QB[p], prev + u * SLOT + 1 * ROLE);
+                    lds_load<NP>(QC[p], prev + ((u + 1) % RING) * SLOT + 2 * ROLE);
                 }
 #pragma unroll
                 for (int p = 0; p < PPS; p++) {
-                    const int u = u0 + p, k = k0 + u;
-                    if (k < W1) {
-                        // ---- four recurrences, minima reduced two directions at a time ----
-                        Pack<NP> N0, NA, NB, NC;
-                        uint32_t r0, rA, rB, rC;
-                        path_elem<NP, PARTIAL>(cb[u], L0, P1s, P2s, active, N0, r0);
-                        path_elem<NP, PARTIAL>(cb[u], QA[p], P1s, P2s, active, NA, rA);
-                        path_elem<NP, PARTIAL>(cb[u], QB[p], P1s, P2s, active, NB, rB);
-                        path_elem<NP, PARTIAL>(cb[u], QC[p], P1s, P2s, active, NC, rC);
-                        const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));  // {min 0, min A}
-                        const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));  // {min B, min C}
-                        Pack<NP> LA, LB, LC;
-                        path_normalise<NP, PARTIAL>(N0, m0A & 0xffffu, active, L0);
-                        path_normalise<NP, PARTIAL>(NA, m0A >> 16, active, LA);
-                        path_normalise<NP, PARTIAL>(NB, mBC & 0xffffu, active, LB);
-                        path_normalise<NP, PARTIAL>(NC, mBC >> 16, active, LC);
-                        // ---- hand the three vertical states to the row below ----
-                        uint32_t *s = mine + u * SLOT;
-                        lds_store<NP>(LA, s + 0 * ROLE);
-                        lds_store<NP>(LB, s + 1 * ROLE);
-                        lds_store<NP>(LC, s + 2 * ROLE);
-                        // ---- S ----
-                        Pack<NP> Sn;
-#pragma unroll
-                        for (int i = 0; i < NP; i++) {
-                            uint32_t v = pk_adds_s(pk_adds_s(N0.r[i], NA.r[i]), pk_adds_s(NB.r[i], NC.r[i]));
-                            if (READS_S) v = pk_adds_s(v, sb[u].r[i]);
-                            Sn.r[i] = v;
-                        }
-                        if (MODE != SWEEP_LAST || a.keepS) {
-                            if (active) Sn.store(Srow + e0 + k * ek);
-                        }
-                        if (MODE == SWEEP_LAST) {
-                            const uint2 rec = wta_pixel<NP, PARTIAL>(Sn, lane, active, D, g.uniq);
-                            if (lane == 0) wrow[k * wk] = rec;
-                        }
-                    }
+                    const int u = u0 + p;
+                    if (full || k0 + u < W1) pixel(cb[u], sb[u], QA[p], QB[p], QC[p], u, k0 + u);
                 }
                 wg_barrier();
             }
@@ -255,7 +266,11 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         load_block(cA, sA, k0 + 2 * PB);
         compute_block(cB, sB, k0 + PB);
     }
-    for (int i = 0; i < 2 * (R - 1 - wave); i++) wg_barrier();
+    // one step after the last real pixel: the virtual pixel W1 (start state) for the row below
+    if (wave < R - 1) {
+        write_start_state(mine, W1 % RING);
+        for (int i = 0; i < 2 * (R - 1 - wave); i++) wg_barrier();
+    }
 }
 
 }  // namespace sgm

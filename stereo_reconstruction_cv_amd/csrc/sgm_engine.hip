@@ -78,6 +78,7 @@ struct sgm_engine {
     int profile = 0;
     int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps
     int sweep_rows = 0;  // rows per band of the sweep (0 = automatic)
+    int debug = 0;       // timing experiments (SweepArgs::dbg)
 
     // shape of the last compute
     int H = 0, W = 0;
@@ -556,6 +557,7 @@ int sgm_set_option(sgm_engine *e, int option, int value)
     else if (option == SGM_OPT_PROFILE) e->profile = value ? 1 : 0;
     else if (option == SGM_OPT_SCHEDULE) e->schedule = value ? 1 : 0;
     else if (option == SGM_OPT_SWEEP_ROWS) e->sweep_rows = std::max(0, value);
+    else if (option == SGM_OPT_DEBUG) e->debug = value;
     else return set_err(SGM_ERR_INVALID_ARG, "unknown option %d", option);
     return SGM_OK;
 }
