@@ -391,15 +391,25 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
                 if (nbands > 1) {
                     if ((rc = stage_begin(e, pass == 0 ? "prepass_dn" : "prepass_up"))) return rc;
-                    // role 0: predecessor one step earlier in the sweep's x order (x - xdir), 1: same
-                    // column, 2: one step later
-                    const int rxs[3] = {xdir, 0, -xdir};
-                    for (int k = 0; k < 3; k++) {
-                        Boundary bd{(int16_t *)e->bndL.p, R, k};
-                        launch_path(g, rxs[k], ydir, PATH_BOUNDARY, C, S, 0, wta, st, bd);
+                    // roles: 0 = predecessor one step earlier in the sweep's x order (x - xdir),
+                    // 1 = same column, 2 = one step later; all three in one wave
+                    {
+                        const bool partial = g.D != 128 * g.NP;
+                        dim3 grid(g.W1), block(64);
+                        int16_t *bl = (int16_t *)e->bndL.p;
+                        if (g.NP == 1) {
+                            if (partial) hipLaunchKernelGGL((k_prepass3<1, true>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
+                            else hipLaunchKernelGGL((k_prepass3<1, false>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
+                        } else if (g.NP == 2) {
+                            if (partial) hipLaunchKernelGGL((k_prepass3<2, true>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
+                            else hipLaunchKernelGGL((k_prepass3<2, false>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
+                        } else {
+                            if (partial) hipLaunchKernelGGL((k_prepass3<4, true>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
+                            else hipLaunchKernelGGL((k_prepass3<4, false>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
+                        }
                     }
                     KCHECK();
-                    if ((rc = stage_end(e, 3))) return rc;
+                    if ((rc = stage_end(e, 1))) return rc;
                 }
                 SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)e->bndL.p, wta, e->keep_aggr};
                 const bool last = pass == npass - 1 && g.mode == 1;
