@@ -129,10 +129,15 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
                                              uint2 *__restrict__ wta, Boundary bd)
 {
     // steps per prefetch block (two blocks in flight); deeper where registers allow
-    constexpr int PB = (MODE == PATH_BOUNDARY || MODE == PATH_FIRST) ? (NP == 4 ? 8 : 16) : 8;
+    constexpr int PB = MODE == PATH_FIRST ? (NP == 4 ? 8 : 16) : 8;
     const int lane = threadIdx.x;
     const int line = blockIdx.x;
     const int W1 = g.W1, D = g.D;
+    if (MODE == PATH_BOUNDARY) {
+        // all three roles in one launch (blockIdx.y): rx = +xdir, 0, -xdir where rx carries xdir
+        bd.slot = blockIdx.y;
+        rx = blockIdx.y == 0 ? rx : (blockIdx.y == 1 ? 0 : -rx);
+    }
     const int nsteps = ry == 0 ? W1 : g.H;
     const bool active = !PARTIAL || (2 * NP * lane < D);
     const int lane_off = active ? 2 * NP * lane : 0;  // idle lanes load lane 0's data (ignored)
