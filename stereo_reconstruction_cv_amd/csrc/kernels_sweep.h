@@ -20,6 +20,7 @@
 // directions these are depends on the sweep direction and is decided on the host.
 #pragma once
 #include "kernels_path.h"
+#include <type_traits>
 
 namespace sgm {
 
@@ -187,16 +188,22 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     const int wk = a.xdir > 0 ? 1 : -1;
     uint2 *const wrow = a.wta + (int64_t)y * g.W + g.minX1 + (a.xdir > 0 ? 0 : W1 - 1);
 
-    auto load_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {
-        const bool full = k0 + PB <= W1;
+    // FULL blocks (all but the last of a row) are straight-line code without guards, so that the
+    // scheduler can interleave the independent chains of the PPS pixels of a step
+    auto load_block_t = [&](auto full_c, Pack<NP> *cb, Pack<NP> *sb, int k0) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
         for (int u = 0; u < PB; u++) {
-            if (full || k0 + u < W1) {
+            if (FULL || k0 + u < W1) {
                 const int e = e0 + (k0 + u) * ek;
                 cb[u].load(Crow + e);
                 if (READS_S) sb[u].load(Srow + e);
             }
         }
+    };
+    auto load_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {
+        if (k0 + PB <= W1) load_block_t(std::true_type{}, cb, sb, k0);
+        else load_block_t(std::false_type{}, cb, sb, k0);
     };
 
     // one pixel: four recurrences (minima reduced two directions at a time), hand-off, S, WTA
@@ -235,11 +242,11 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         }
     };
 
-    auto compute_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {  // k0 is a multiple of PB = RING
-        const bool full = k0 + PB <= W1;  // all blocks but the last: straight-line code, no guards
+    auto compute_block_t = [&](auto full_c, Pack<NP> *cb, Pack<NP> *sb, int k0) {  // k0 % PB == 0
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
         for (int u0 = 0; u0 < PB; u0 += PPS) {
-            if (full || k0 + u0 < W1) {
+            if (FULL || k0 + u0 < W1) {
                 // normalised state of the row above for the PPS pixels of this step (LDS)
                 Pack<NP> QA[PPS], QB[PPS], QC[PPS];
 #pragma unroll
@@ -252,11 +259,15 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
 #pragma unroll
                 for (int p = 0; p < PPS; p++) {
                     const int u = u0 + p;
-                    if (full || k0 + u < W1) pixel(cb[u], sb[u], QA[p], QB[p], QC[p], u, k0 + u);
+                    if (FULL || k0 + u < W1) pixel(cb[u], sb[u], QA[p], QB[p], QC[p], u, k0 + u);
                 }
                 wg_barrier();
             }
         }
+    };
+    auto compute_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {
+        if (k0 + PB <= W1) compute_block_t(std::true_type{}, cb, sb, k0);
+        else compute_block_t(std::false_type{}, cb, sb, k0);
     };
 
     load_block(cA, sA, 0);
