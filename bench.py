@@ -38,7 +38,7 @@ WORKLOADS = {
     "c3": (2160, 3840, 256, 7, 1, 1, False, "3840x2160 D=256 bs=7 8-path (configs[2])"),
     "c4": (1080, 1920, 128, 7, 0, 8, False, "8x 1920x1080 D=128 bs=7 5-path per GPU (configs[3])"),
     "c5": (2160, 3840, 256, 7, 0, 1, True, "3840x2160 D=256 bs=7 5-path + reproject (configs[4])"),
-    "c3c5": (2160, 3840, 256, 7, 1, 1, True,
+    "c3c5": (2160, 3840, 256, 7, 1, 2, True,
              "3840x2160 D=256 bs=7 MODE_HH 8-path + LR + subpixel + median + speckle + reprojectImageTo3D"),
     "nb": (2160, 3840, 16, 11, 0, 1, True, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
 }
@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline runs (0 = auto)")
     ap.add_argument("--verify", action="store_true", help="also run the oracle on the full frame and compare")
     ap.add_argument("--stages", action="store_true", help="print the per-stage HIP-event table to stderr")
+    ap.add_argument("--concurrent", type=int, default=0,
+                    help="engines (HIP streams) working on different pairs at the same time; 0 = workload default")
+    ap.add_argument("--schedule", type=int, default=1, help="0: one kernel per path direction, 1: fused sweeps")
     args = ap.parse_args()
 
     import torch
@@ -94,16 +97,27 @@ def main():
     d_xyz = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(ppg)] if with_xyz else None
     torch.cuda.synchronize(dev)
 
-    eng = cv.Engine(p, device=local_rank)
-    eng.set_option(_lib.SGM_OPT_PROFILE, 1)
+    # `nconc` engines = HIP streams; pair i of a step runs on engine i % nconc, so independent
+    # pairs overlap on the GPU (each engine owns its own device buffers)
+    nconc = max(1, min(args.concurrent or ppg, ppg))
+    engines = []
+    for _ in range(nconc):
+        e = cv.Engine(p, device=local_rank)
+        e.set_option(_lib.SGM_OPT_PROFILE, 1)
+        e.set_option(_lib.SGM_OPT_SCHEDULE, args.schedule)
+        engines.append(e)
+    eng = engines[0]
 
     def step():
         acc = []
-        for i in range(ppg):
-            eng.pipeline_device(d_left[i].data_ptr(), d_right[i].data_ptr(), H, W, W, Q if with_xyz else None,
-                                d_disp[i].data_ptr(), d_dispf[i].data_ptr() if with_xyz else None,
-                                d_xyz[i].data_ptr() if with_xyz else None)
-            acc.append(eng.stage_times())  # HIP events on the engine's stream; synchronises it
+        for i0 in range(0, ppg, nconc):
+            group = range(i0, min(i0 + nconc, ppg))
+            for i in group:  # enqueue on every stream first ...
+                engines[i % nconc].pipeline_device(
+                    d_left[i].data_ptr(), d_right[i].data_ptr(), H, W, W, Q if with_xyz else None, d_disp[i].data_ptr(),
+                    d_dispf[i].data_ptr() if with_xyz else None, d_xyz[i].data_ptr() if with_xyz else None)
+            for i in group:  # ... then collect the HIP-event stage times (synchronises that stream)
+                acc.append(engines[i % nconc].stage_times())
         return acc
 
     def barrier():
@@ -135,19 +149,31 @@ def main():
             print(f"  {n:<14s} {m:9.4f} ms", file=sys.stderr)
         print(f"  {'sum':<14s} {mean_ms.sum():9.4f} ms   wall/frame {dt / args.steps / ppg * 1e3:9.4f} ms", file=sys.stderr)
 
-    # dominant kernel: the accumulate instance of the path kernel (k_path<NP, *, PATH_ACCUM>),
-    # one launch per stage; algorithmic bytes per launch = 3 V (read C, read S, write S).
+    # dominant kernel = the stage with the largest HIP-event time.  Algorithmic bytes of a launch
+    # follow the SURVEY.md 8(d) model: a path scan is 3 V (read C, read S, write S); a fused sweep
+    # launch performs four path scans = 12 V; the boundary pre-pass has no counterpart in the model
+    # (extra work of this design, 0 algorithmic bytes); the cost stage writes V.
     _, W1 = eng.geometry(W)
     V = 2 * H * W1 * D
-    accum = [i for i, n in enumerate(names) if n.startswith("path_") and n not in ("path_S", "path_W_wta")]
-    k_ms = float(mean_ms[accum].mean())
-    achieved = 3 * V / (k_ms * 1e-3) / 1e9
+    alg = {}
+    for n in names:
+        if n.startswith("sweep_"):
+            alg[n] = 12 * V
+        elif n.startswith("path_"):
+            alg[n] = 3 * V
+        elif n in ("cost_hsum", "cost_vsum"):
+            alg[n] = V // 2
+    dom = max(alg, key=lambda n: mean_ms[names.index(n)])
+    k_ms = float(mean_ms[names.index(dom)])
+    achieved = alg[dom] / (k_ms * 1e-3) / 1e9
+    kname = {"sweep_dn": "k_sweep<NP,*,SWEEP_FIRST>", "sweep_up_wta": "k_sweep<NP,*,SWEEP_LAST>",
+             "path_W_wta": "k_path<NP,*,PATH_LAST>"}.get(dom, "k_path<NP,*,PATH_ACCUM>" if dom.startswith("path_") else dom)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            if rec.get("workload") == args.workload:
+            if rec.get("workload") == args.workload and rec.get("stage") == dom:
                 traffic = rec.get("traffic_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
@@ -171,13 +197,17 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "height": H, "width": W, "numDisparities": D,
                    "blockSize": bs, "mode": "MODE_HH" if mode else "MODE_SGBM", "pairs_per_gpu_per_step": ppg,
-                   "global_pairs_per_step": ppg * world, "parallelism": f"frame-sharded x{world}, no data-path collective"},
+                   "global_pairs_per_step": ppg * world, "streams_per_gpu": nconc,
+                   "schedule": "fused sweeps" if args.schedule else "one kernel per direction",
+                   "parallelism": f"frame-sharded x{world}, no data-path collective"},
         "pairs_per_s": frames / dt,
         "algorithmic_GBps_whole_step": alg_bytes * ppg * world / (dt / args.steps) / 1e9,
-        "roofline": {"bound": "hbm", "kernel": f"k_path<NP={2 if 128 < D <= 256 else (1 if D <= 128 else 4)},PATH_ACCUM>",
+        "roofline": {"bound": "hbm", "kernel": kname, "stage": dom,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": 3 * V, "avg_launch_ms": k_ms,
-                     "launches_per_step": len(accum) * ppg},
+                     "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": k_ms,
+                     "launches_per_step": ppg,
+                     "note": "achieved = algorithmic bytes of the unfused SURVEY 8(d) model / measured launch time; "
+                             "the fused kernel moves fewer real bytes (traffic), so frac can exceed 1"},
         "stage_ms": {n: float(m) for n, m in zip(names, mean_ms)},
     }
 

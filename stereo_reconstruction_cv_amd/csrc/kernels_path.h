@@ -81,14 +81,26 @@ __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool ac
     if (PARTIAL && !active) kmin = 0xffffffffu;
     const uint32_t key = wave_min_u32(kmin);  // (minS << 16) | first best d
     const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
-    const int thr = minS * 100, wgt = 100 - uniq;
+    // S * (100 - uniq) < minS * 100 with S, minS < 2^15 and a weight in [0, 100]: 24-bit products
+    // (v_mul_u32_u24 is full rate, v_mul_lo_u32 quarter rate).  uniq > 100 makes the weight
+    // negative upstream: the product is then <= 0 and the test reads S * w < thr in signed terms.
+    const int wgt = 100 - uniq;
+    const uint32_t thr = __umul24((uint32_t)minS, 100u);
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const int d0 = 2 * (NP * lane + i);
-        const int slo = (int)(Sn.r[i] & 0xffffu), shi = (int)(Sn.r[i] >> 16);
-        bad |= (slo * wgt < thr) && (abs(best - d0) > 1);
-        bad |= (shi * wgt < thr) && (abs(best - d0 - 1) > 1);
+        const uint32_t slo = Sn.r[i] & 0xffffu, shi = Sn.r[i] >> 16;
+        bool lo_lt, hi_lt;
+        if (wgt >= 0) {
+            lo_lt = __umul24(slo, (uint32_t)wgt) < thr;
+            hi_lt = __umul24(shi, (uint32_t)wgt) < thr;
+        } else {
+            lo_lt = (int)slo * wgt < (int)thr;
+            hi_lt = (int)shi * wgt < (int)thr;
+        }
+        bad |= lo_lt && (abs(best - d0) > 1);
+        bad |= hi_lt && (abs(best - d0 - 1) > 1);
     }
     if (PARTIAL) bad = bad && active;
     bool reject = __builtin_amdgcn_ballot_w64(bad) != 0ull;

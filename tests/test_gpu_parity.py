@@ -242,3 +242,13 @@ def test_speckle_filter_large_frame():
     got = eng.filter_speckles_host(img, -16, 100, 16)
     want = O.filter_speckles(img, -16, 100, 16)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("uniq", [0, 1, 55, 100, 150])
+def test_uniqueness_ratio_edges(uniq):
+    l, r, _ = synth.make_pair(40, 260, 64, 71)
+    for mode in (0, 1):
+        p = U.params(64, 5, 0, mode, uniquenessRatio=uniq)
+        rep, t, h = U.compare_stages(l, r, p)
+        bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
+        assert not bad, f"uniq={uniq} mode={mode}: " + "\n".join(bad)
