@@ -38,8 +38,10 @@ WORKLOADS = {
     "c3": (2160, 3840, 256, 7, 1, 1, False, "3840x2160 D=256 bs=7 8-path (configs[2])"),
     "c4": (1080, 1920, 128, 7, 0, 8, False, "8x 1920x1080 D=128 bs=7 5-path per GPU (configs[3])"),
     "c5": (2160, 3840, 256, 7, 0, 1, True, "3840x2160 D=256 bs=7 5-path + reproject (configs[4])"),
-    "c3c5": (2160, 3840, 256, 7, 1, 2, True,
+    "c3c5": (2160, 3840, 256, 7, 1, 1, True,
              "3840x2160 D=256 bs=7 MODE_HH 8-path + LR + subpixel + median + speckle + reprojectImageTo3D"),
+    "c3c5x2": (2160, 3840, 256, 7, 1, 2, True,
+               "two concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on two HIP streams (+ reproject)"),
     "nb": (2160, 3840, 16, 11, 0, 1, True, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
 }
 
