@@ -232,4 +232,43 @@ __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, in
     }
 }
 
+// Same vertical box sum, each hsum row read ONCE: the last 2*SH2+2 rows of the column live in a
+// register ring (statically indexed: bands start at multiples of RS and the row loop is unrolled
+// by RS).  Instantiated for the common block sizes; other sizes use k_vsum.
+template <int SH2_>
+__global__ __launch_bounds__(256) void k_vsum_ring(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
+                                                   int H, int64_t rowsz, int RB /* multiple of RS */)
+{
+    constexpr int RS = SH2_ <= 1 ? 4 : (SH2_ <= 3 ? 8 : (SH2_ <= 7 ? 16 : 32));  // pow2 >= 2*SH2+2
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // 4 int16 per thread
+    if (e >= rowsz) return;
+    const int y0 = blockIdx.y * RB, y1 = min(y0 + RB, H);
+    uint2 ring[RS];
+    uint2 acc = make_uint2(0, 0);
+    auto ld = [&](int r) { return *reinterpret_cast<const uint2 *>(hs + (int64_t)min(max(r, 0), H - 1) * rowsz + e); };
+    // window of row y0: rows y0-SH2 .. y0+SH2 (y0 % RS == 0, so slot(y0 + j) = j & (RS-1) is static)
+#pragma unroll
+    for (int j = -SH2_; j <= SH2_; j++) {
+        const uint2 v = ld(y0 + j);
+        ring[j & (RS - 1)] = v;
+        acc.x = pk_add(acc.x, v.x);
+        acc.y = pk_add(acc.y, v.y);
+    }
+    *reinterpret_cast<uint2 *>(C + (int64_t)y0 * rowsz + e) = acc;
+    for (int yb = y0; yb < y1; yb += RS) {
+#pragma unroll
+        for (int u = 0; u < RS; u++) {
+            const int y = yb + u;
+            if (y > y0 && y < y1) {
+                const uint2 v = ld(y + SH2_);
+                const uint2 o = ring[(u - SH2_ - 1) & (RS - 1)];
+                acc.x = pk_sub(pk_add(acc.x, v.x), o.x);
+                acc.y = pk_sub(pk_add(acc.y, v.y), o.y);
+                ring[(u + SH2_) & (RS - 1)] = v;
+                *reinterpret_cast<uint2 *>(C + (int64_t)y * rowsz + e) = acc;
+            }
+        }
+    }
+}
+
 }  // namespace sgm

@@ -343,9 +343,21 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // -- vertical box sum -> block cost
         if ((rc = stage_begin(e, "cost_vsum"))) return rc;
         {
-            const int RB = 64;
-            dim3 grid((unsigned)((g.rowsz / 8 + 255) / 256), (H + RB - 1) / RB), block(256);
-            hipLaunchKernelGGL(k_vsum, grid, block, 0, st, (const int16_t *)HS, (int16_t *)e->cost.p, H, g.rowsz, g.SH2, RB);
+            const int RB = 96;  // multiple of every ring size used below
+            const int16_t *hsp = (const int16_t *)HS;
+            int16_t *cp = (int16_t *)e->cost.p;
+            dim3 block(256), gridr((unsigned)((g.rowsz / 4 + 255) / 256), (H + RB - 1) / RB);
+            switch (g.SH2) {  // ring variant: each hsum row is read once
+            case 1: hipLaunchKernelGGL(k_vsum_ring<1>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
+            case 2: hipLaunchKernelGGL(k_vsum_ring<2>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
+            case 3: hipLaunchKernelGGL(k_vsum_ring<3>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
+            case 4: hipLaunchKernelGGL(k_vsum_ring<4>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
+            case 5: hipLaunchKernelGGL(k_vsum_ring<5>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
+            default: {
+                dim3 grid((unsigned)((g.rowsz / 8 + 255) / 256), (H + 63) / 64);
+                hipLaunchKernelGGL(k_vsum, grid, block, 0, st, hsp, cp, H, g.rowsz, g.SH2, 64);
+            }
+            }
             KCHECK();
         }
         if ((rc = stage_end(e, 1))) return rc;
