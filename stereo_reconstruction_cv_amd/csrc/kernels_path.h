@@ -259,8 +259,12 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
 // Boundary pre-pass for k_sweep, all three roles in one wave: line `blockIdx.x` of each of the
 // directions (rx = +xdir, 0, -xdir; ry = ydir) is advanced together, one image row per step.
 // Three independent dependency chains per wave (the scheduler interleaves them) and the three
-// reads of a cost row land close together in time, so two of them are served by L2 / MALL.
+// reads of a cost row land close together in time, so two of them can be served by L2 / MALL.
 // Only the normalised state at band boundaries is stored (Boundary layout above).
+//
+// Blocks of PB rows in which no diagonal leaves the image run as straight-line code (constant
+// address strides, no cursor arithmetic); the rare blocks with a wrap take the per-step path.
+// Offsets are 32-bit element indices (the host checks H * W1 * D < 2^31).
 template <int NP, bool PARTIAL>
 __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
                                                  int16_t *__restrict__ bndL, int R)
@@ -274,81 +278,137 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     const uint32_t init = active ? 0u : SGM_SENT;
     const int rx[3] = {xdir, 0, -xdir};
-    const int64_t row_off = (int64_t)W1 * D;
-    const int64_t ystep = (int64_t)ydir * row_off;
+    const int row_off = W1 * D;
+    int stride[3];  // element stride of one step of each role
+#pragma unroll
+    for (int d = 0; d < 3; d++) stride[d] = ydir * row_off + rx[d] * D;
+    const int16_t *const Cl = C + lane_off;
 
-    // per role: column of the load cursor / compute cursor; the row is common
-    int xl[3], xc[3];
-    int64_t offl[3];
+    // per role: column and element offset of the next pixel of the load / compute cursors
+    int xl[3], xc[3], offl[3];
     const int y0 = ydir > 0 ? 0 : H - 1;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         xl[d] = xc[d] = line;
-        offl[d] = ((int64_t)y0 * W1 + line) * D;
+        offl[d] = (y0 * W1 + line) * D;
     }
     Pack<NP> L[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) L[d].fill(init);
     Pack<NP> cA[PB][3], cB[PB][3];
 
+    // does role d stay inside [0, W1) for the PB steps starting at column x ?
+    auto stays = [&](int x, int d) { const int xe = x + (PB - 1) * rx[d]; return xe >= 0 && xe < W1; };
+
     auto load_block = [&](Pack<NP>(*cb)[3], int step0) {
-        const bool full = step0 + PB <= H;
+        if (step0 >= H) return;
+        if (step0 + PB <= H && stays(xl[0], 0) && stays(xl[2], 2)) {
 #pragma unroll
-        for (int k = 0; k < PB; k++) {
-            if (full || step0 + k < H) {
+            for (int k = 0; k < PB; k++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) cb[k][d].load(Cl + (offl[d] + k * stride[d]));
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                xl[d] += PB * rx[d];
+                offl[d] += PB * stride[d];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PB; k++) {
+                if (step0 + k < H) {
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        cb[k][d].load(Cl + offl[d]);
+                        xl[d] += rx[d];
+                        offl[d] += stride[d];
+                    }
+                }
+                // a column index that left the image re-enters on the other side (next row)
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    cb[k][d].load(C + offl[d] + lane_off);
-                    xl[d] += rx[d];
-                    offl[d] += ystep + (int64_t)rx[d] * D;
                     if (xl[d] >= W1) {
-                        xl[d] = 0;
+                        xl[d] -= W1;
                         offl[d] -= row_off;
                     } else if (xl[d] < 0) {
-                        xl[d] = W1 - 1;
+                        xl[d] += W1;
                         offl[d] += row_off;
                     }
                 }
             }
         }
+        // normalise a cursor that stands exactly one past the border after a straight block
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if (xl[d] >= W1) {
+                xl[d] -= W1;
+                offl[d] -= row_off;
+            } else if (xl[d] < 0) {
+                xl[d] += W1;
+                offl[d] += row_off;
+            }
+        }
     };
 
     int to_boundary = R - 1, next_band = 1;
+    auto one_step = [&](Pack<NP> *c3, bool store_ok) {
+        Pack<NP> N[3];
+        uint32_t r[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) path_elem<NP, PARTIAL>(c3[d], L[d], P1s, P2s, active, N[d], r[d]);
+        const uint32_t m01 = wave_min_pk(pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])));
+        const uint32_t m2 = halves_min(wave_min_pk(r[2]));
+        path_normalise<NP, PARTIAL>(N[0], m01 & 0xffffu, active, L[0]);
+        path_normalise<NP, PARTIAL>(N[1], m01 >> 16, active, L[1]);
+        path_normalise<NP, PARTIAL>(N[2], m2, active, L[2]);
+        if (to_boundary == 0) {
+            if (store_ok && active) {
+#pragma unroll
+                for (int d = 0; d < 3; d++)
+                    L[d].store(bndL + (((int64_t)next_band * W1 + xc[d]) * 3 + d) * D + lane_off);
+            }
+            to_boundary = R;
+            next_band++;
+        }
+        to_boundary--;
+    };
+
     auto compute_block = [&](Pack<NP>(*cb)[3], int step0) {
-        const bool full = step0 + PB <= H;
+        if (step0 >= H) return;
+        if (step0 + PB <= H && stays(xc[0], 0) && stays(xc[2], 2)) {
 #pragma unroll
-        for (int k = 0; k < PB; k++) {
-            if (full || step0 + k < H) {
-                Pack<NP> N[3];
-                uint32_t r[3];
+            for (int k = 0; k < PB; k++) {
+                one_step(cb[k], step0 + k + 1 < H);
 #pragma unroll
-                for (int d = 0; d < 3; d++) path_elem<NP, PARTIAL>(cb[k][d], L[d], P1s, P2s, active, N[d], r[d]);
-                const uint32_t m01 = wave_min_pk(pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])));
-                const uint32_t m2 = halves_min(wave_min_pk(r[2]));
-                path_normalise<NP, PARTIAL>(N[0], m01 & 0xffffu, active, L[0]);
-                path_normalise<NP, PARTIAL>(N[1], m01 >> 16, active, L[1]);
-                path_normalise<NP, PARTIAL>(N[2], m2, active, L[2]);
-                if (to_boundary == 0) {
-                    if (step0 + k + 1 < H && active) {
+                for (int d = 0; d < 3; d++) xc[d] += rx[d];
+            }
+        } else {
 #pragma unroll
-                        for (int d = 0; d < 3; d++)
-                            L[d].store(bndL + (((int64_t)next_band * W1 + xc[d]) * 3 + d) * D + lane_off);
-                    }
-                    to_boundary = R;
-                    next_band++;
-                }
-                to_boundary--;
+            for (int k = 0; k < PB; k++) {
+                if (step0 + k < H) {
+                    one_step(cb[k], step0 + k + 1 < H);
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    xc[d] += rx[d];
-                    if (xc[d] >= W1) {
-                        xc[d] = 0;
-                        L[d].fill(init);
-                    } else if (xc[d] < 0) {
-                        xc[d] = W1 - 1;
-                        L[d].fill(init);
+                    for (int d = 0; d < 3; d++) {
+                        xc[d] += rx[d];
+                        if (xc[d] >= W1) {
+                            xc[d] = 0;
+                            L[d].fill(init);
+                        } else if (xc[d] < 0) {
+                            xc[d] = W1 - 1;
+                            L[d].fill(init);
+                        }
                     }
                 }
+            }
+        }
+        // a line that reached the border exactly at the end of a straight block restarts here
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if (xc[d] >= W1) {
+                xc[d] = 0;
+                L[d].fill(init);
+            } else if (xc[d] < 0) {
+                xc[d] = W1 - 1;
+                L[d].fill(init);
             }
         }
     };

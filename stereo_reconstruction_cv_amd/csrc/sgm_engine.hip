@@ -405,8 +405,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     if ((rc = stage_begin(e, pass == 0 ? "prepass_dn" : "prepass_up"))) return rc;
                     // roles: 0 = predecessor one step earlier in the sweep's x order (x - xdir),
                     // 1 = same column, 2 = one step later
-                    if (e->debug & 16) {
-                        // variant: the three roles fused in one wave (k_prepass3)
+                    if (!(e->debug & 16) && (int64_t)g.rowsz * H < (1ll << 31)) {
+                        // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant
                         const bool partial = g.D != 128 * g.NP;
                         dim3 grid(g.W1), block(64);
                         int16_t *bl = (int16_t *)e->bndL.p;
@@ -421,7 +421,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                             else hipLaunchKernelGGL((k_prepass3<4, false>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
                         }
                     } else {
-                        // one launch, grid.y = role: three times the waves in flight to hide HBM latency
+                        // one launch of the single-direction kernel, grid.y = role
                         Boundary bd{(int16_t *)e->bndL.p, R, 0};
                         launch_path(g, xdir, ydir, PATH_BOUNDARY, C, S, 0, wta, st, bd);
                     }
