@@ -143,6 +143,7 @@ def main():
         dt = float(t.item())
 
     # ---- per-stage HIP-event durations (this rank) ----
+    stage_acc = [[t for t in st if t[0] != "_wall"] for st in stage_acc]
     names = [n for n, _, _ in stage_acc[0]]
     ms = np.array([[m for _, m, _ in st] for st in stage_acc])  # [frames][stages]
     mean_ms = ms.mean(axis=0)

@@ -74,6 +74,8 @@ struct sgm_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux = nullptr;            // second stream: MODE_HH overlaps the upward pre-pass with the downward sweep
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int keep_aggr = 0;
     int profile = 0;
     int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps
@@ -88,7 +90,7 @@ struct sgm_engine {
     DevBuf lrec, rplanes;               // features
     DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
     DevBuf wta;                         // uint2 [H][W]
-    DevBuf bndL;                        // band-boundary state of the sweep pre-pass
+    DevBuf bndL, bndL2;                 // band-boundary state of the sweep pre-pass (down / up)
     DevBuf disp_raw, disp_med, disp_out;  // int16 [H][W]
     DevBuf label, csize, rlen;          // int32 [H][W] each
     DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
@@ -132,7 +134,7 @@ static int normalise(const sgm_params *p, int H, int W, Geom *g)
 }
 
 // ---- stage bookkeeping -----------------------------------------------------------------------
-static int stage_begin(sgm_engine *e, const char *name)
+static int stage_begin(sgm_engine *e, const char *name, hipStream_t on = nullptr)
 {
     if (!e->profile) return SGM_OK;
     if (e->nstages >= SGM_MAX_STAGES) return SGM_OK;
@@ -146,15 +148,15 @@ static int stage_begin(sgm_engine *e, const char *name)
     e->stage_launches.resize(e->nstages + 1);
     e->stage_names[e->nstages] = name;
     e->stage_launches[e->nstages] = 0;
-    HIP_TRY(hipEventRecord(e->events[e->nstages * 2], e->stream));
+    HIP_TRY(hipEventRecord(e->events[e->nstages * 2], on ? on : e->stream));
     return SGM_OK;
 }
-static int stage_end(sgm_engine *e, int launches)
+static int stage_end(sgm_engine *e, int launches, hipStream_t on = nullptr)
 {
     if (!e->profile) return SGM_OK;
     if (e->nstages >= SGM_MAX_STAGES) return SGM_OK;
     e->stage_launches[e->nstages] = launches;
-    HIP_TRY(hipEventRecord(e->events[e->nstages * 2 + 1], e->stream));
+    HIP_TRY(hipEventRecord(e->events[e->nstages * 2 + 1], on ? on : e->stream));
     e->nstages++;
     return SGM_OK;
 }
@@ -395,40 +397,63 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // -- fused schedule: per pass a read-only boundary pre-pass (3 line scans) + one sweep
             const int R = sweep_rows_for(g, e->sweep_rows);
             const int nbands = (H + R - 1) / R;
-            if (nbands > 1) {
-                if ((rc = e->bndL.ensure((size_t)nbands * g.W1 * 3 * g.D * 2))) return rc;
-            }
             const int npass = g.mode == 1 ? 2 : 1;
+            const size_t bnd_bytes = (size_t)nbands * g.W1 * 3 * g.D * 2;
+            if (nbands > 1) {
+                if ((rc = e->bndL.ensure(bnd_bytes))) return rc;
+                if (npass == 2 && (rc = e->bndL2.ensure(bnd_bytes))) return rc;
+            }
+            // roles of the pre-pass: 0 = predecessor one step earlier in the sweep's x order
+            // (x - xdir), 1 = same column, 2 = one step later
+            auto launch_prepass = [&](int xdir, int ydir, int16_t *bl, hipStream_t on) {
+                if (!(e->debug & 16) && (int64_t)g.rowsz * H < (1ll << 31)) {
+                    // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant
+                    const bool partial = g.D != 128 * g.NP;
+                    dim3 grid(g.W1), block(64);
+                    if (g.NP == 1) {
+                        if (partial) hipLaunchKernelGGL((k_prepass3<1, true>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
+                        else hipLaunchKernelGGL((k_prepass3<1, false>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
+                    } else if (g.NP == 2) {
+                        if (partial) hipLaunchKernelGGL((k_prepass3<2, true>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
+                        else hipLaunchKernelGGL((k_prepass3<2, false>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
+                    } else {
+                        if (partial) hipLaunchKernelGGL((k_prepass3<4, true>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
+                        else hipLaunchKernelGGL((k_prepass3<4, false>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
+                    }
+                } else {
+                    // one launch of the single-direction kernel, grid.y = role
+                    Boundary bd{bl, R, 0};
+                    launch_path(g, xdir, ydir, PATH_BOUNDARY, C, S, 0, wta, on, bd);
+                }
+            };
+            // MODE_HH: the upward pre-pass only reads C, so it runs on the auxiliary stream while the
+            // main stream does the downward pre-pass and sweep (memory-bound beside issue-bound work)
+            const bool overlap = npass == 2 && nbands > 1 && !(e->debug & 32);
+            if (overlap) {
+                if (!e->aux) {
+                    HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(e->ev_fork, st));
+                HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+                if ((rc = stage_begin(e, "prepass_up", e->aux))) return rc;
+                launch_prepass(-1, -1, (int16_t *)e->bndL2.p, e->aux);
+                KCHECK();
+                if ((rc = stage_end(e, 1, e->aux))) return rc;
+                HIP_TRY(hipEventRecord(e->ev_join, e->aux));
+            }
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
-                if (nbands > 1) {
+                int16_t *bl = (int16_t *)(pass == 0 ? e->bndL.p : e->bndL2.p);
+                if (nbands > 1 && !(overlap && pass == 1)) {
                     if ((rc = stage_begin(e, pass == 0 ? "prepass_dn" : "prepass_up"))) return rc;
-                    // roles: 0 = predecessor one step earlier in the sweep's x order (x - xdir),
-                    // 1 = same column, 2 = one step later
-                    if (!(e->debug & 16) && (int64_t)g.rowsz * H < (1ll << 31)) {
-                        // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant
-                        const bool partial = g.D != 128 * g.NP;
-                        dim3 grid(g.W1), block(64);
-                        int16_t *bl = (int16_t *)e->bndL.p;
-                        if (g.NP == 1) {
-                            if (partial) hipLaunchKernelGGL((k_prepass3<1, true>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
-                            else hipLaunchKernelGGL((k_prepass3<1, false>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
-                        } else if (g.NP == 2) {
-                            if (partial) hipLaunchKernelGGL((k_prepass3<2, true>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
-                            else hipLaunchKernelGGL((k_prepass3<2, false>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
-                        } else {
-                            if (partial) hipLaunchKernelGGL((k_prepass3<4, true>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
-                            else hipLaunchKernelGGL((k_prepass3<4, false>), grid, block, 0, st, g, xdir, ydir, C, bl, R);
-                        }
-                    } else {
-                        // one launch of the single-direction kernel, grid.y = role
-                        Boundary bd{(int16_t *)e->bndL.p, R, 0};
-                        launch_path(g, xdir, ydir, PATH_BOUNDARY, C, S, 0, wta, st, bd);
-                    }
+                    launch_prepass(xdir, ydir, bl, st);
                     KCHECK();
                     if ((rc = stage_end(e, 1))) return rc;
                 }
-                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)e->bndL.p, wta, e->keep_aggr};
+                if (overlap && pass == 1) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr};
                 const bool last = pass == npass - 1 && g.mode == 1;
                 if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : "sweep_up_wta"))) return rc;
                 if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) return rc;
@@ -568,11 +593,17 @@ void sgm_destroy(sgm_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta, &e->bndL,
+    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta, &e->bndL, &e->bndL2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
                       &e->minkey};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->aux) {
+        (void)hipStreamSynchronize(e->aux);
+        (void)hipEventDestroy(e->ev_fork);
+        (void)hipEventDestroy(e->ev_join);
+        (void)hipStreamDestroy(e->aux);
+    }
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -808,6 +839,15 @@ int sgm_get_stage_times(sgm_engine *e, sgm_stage_times *out)
         out->name[i] = e->stage_names[i];
         out->ms[i] = ms;
         out->launches[i] = e->stage_launches[i];
+    }
+    // stages may overlap (auxiliary stream): also report first-begin -> last-end of the main stream
+    if (e->nstages > 0 && e->nstages < SGM_MAX_STAGES) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->events[0], e->events[(e->nstages - 1) * 2 + 1]));
+        out->name[e->nstages] = "_wall";
+        out->ms[e->nstages] = ms;
+        out->launches[e->nstages] = 0;
+        out->n = e->nstages + 1;
     }
     return SGM_OK;
 }

@@ -34,4 +34,5 @@ for rnd in range(6):
         names = [n for n, _, _ in st]
 for v in variants:
     a = np.median(np.array(acc[v]), axis=0)
-    print(f"debug={v:3d} total {a.sum():6.2f} ms  " + " ".join(f"{n}={m:.2f}" for n, m in zip(names, a) if m > 0.25), flush=True)
+    wall = a[names.index("_wall")] if "_wall" in names else a.sum()
+    print(f"debug={v:3d} wall {wall:6.2f} ms  " + " ".join(f"{n}={m:.2f}" for n, m in zip(names, a) if m > 0.25 and n != "_wall"), flush=True)
