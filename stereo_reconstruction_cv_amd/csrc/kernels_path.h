@@ -67,6 +67,12 @@ __device__ __forceinline__ void path_normalise(const Pack<NP> &Ln, uint32_t m, b
 
 // Winner-take-all on the finished S of one pixel (A.6 steps 1-2; steps 3-4 run in k_select):
 // returns the record {reject ? ~0 : (minS << 16 | first best d), S[best-1] | S[best+1] << 16}.
+//
+// Uniqueness (upstream: reject if some d with |d - best| > 1 has S[d]*(100-uniq) < minS*100):
+// for a positive weight that is "the smallest S outside {best-1, best, best+1}, times the
+// weight, is below minS*100" -- one more packed wave reduction instead of per-element products
+// and boolean mask arithmetic.  Non-positive weights (uniquenessRatio >= 100) take the literal
+// per-element form.
 template <int NP, bool PARTIAL>
 __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool active, int D, int uniq)
 {
@@ -81,39 +87,49 @@ __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool ac
     if (PARTIAL && !active) kmin = 0xffffffffu;
     const uint32_t key = wave_min_u32(kmin);  // (minS << 16) | first best d
     const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
-    // S * (100 - uniq) < minS * 100 with S, minS < 2^15 and a weight in [0, 100]: 24-bit products
-    // (v_mul_u32_u24 is full rate, v_mul_lo_u32 quarter rate).  uniq > 100 makes the weight
-    // negative upstream: the product is then <= 0 and the test reads S * w < thr in signed terms.
     const int wgt = 100 - uniq;
-    const uint32_t thr = __umul24((uint32_t)minS, 100u);
-    bool bad = false;
+    const int thr = minS * 100;
+    bool reject;
+    if (wgt > 0) {
+        uint32_t far = SGM_SENT;
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-        const int d0 = 2 * (NP * lane + i);
-        const uint32_t slo = Sn.r[i] & 0xffffu, shi = Sn.r[i] >> 16;
-        bool lo_lt, hi_lt;
-        if (wgt >= 0) {
-            lo_lt = __umul24(slo, (uint32_t)wgt) < thr;
-            hi_lt = __umul24(shi, (uint32_t)wgt) < thr;
-        } else {
-            lo_lt = (int)slo * wgt < (int)thr;
-            hi_lt = (int)shi * wgt < (int)thr;
+        for (int i = 0; i < NP; i++) {
+            // e = d_lo - (best - 1): the low half is near best for e in {0,1,2}, the high half
+            // (d_lo + 1) for e in {-1,0,1}; S <= 0x7fff, so OR-ing 0x7fff makes a half "infinite"
+            const int e = 2 * (NP * lane + i) - best + 1;
+            uint32_t v = Sn.r[i];
+            v |= ((uint32_t)e <= 2u) ? 0x00007fffu : 0u;
+            v |= ((uint32_t)(e + 1) <= 2u) ? 0x7fff0000u : 0u;
+            far = pk_min_s(far, v);
         }
-        bad |= lo_lt && (abs(best - d0) > 1);
-        bad |= hi_lt && (abs(best - d0 - 1) > 1);
+        if (PARTIAL && !active) far = SGM_SENT;
+        const int m2 = (int)halves_min(wave_min_pk(far));  // D >= 16: far disparities always exist
+        reject = m2 * wgt < thr;
+    } else {
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int d0 = 2 * (NP * lane + i);
+            const int slo = (int)(Sn.r[i] & 0xffffu), shi = (int)(Sn.r[i] >> 16);
+            bad |= (__mul24(slo, wgt) < thr) && (abs(best - d0) > 1);
+            bad |= (__mul24(shi, wgt) < thr) && (abs(best - d0 - 1) > 1);
+        }
+        if (PARTIAL) bad = bad && active;
+        reject = __builtin_amdgcn_ballot_w64(bad) != 0ull;
     }
-    if (PARTIAL) bad = bad && active;
-    bool reject = __builtin_amdgcn_ballot_w64(bad) != 0ull;
     // all costs saturated: upstream keeps bestDisp = -1; the pixel ends invalid and never wins
     // a right-view slot (32767 > 32767 is false)
     reject = reject || (minS == SGM_MAX_COST);
+    // S[best-1], S[best+1]: lane (d / 2NP) holds d; read the lane's registers, pick the half
     auto fetch = [&](int d) -> uint32_t {
-        const int p = d >> 1, ln = p / NP, i = p - ln * NP;
-        uint32_t v = Sn.r[0];
+        const int ln = d / (2 * NP), e = d - ln * (2 * NP);  // element e of lane ln
+        uint32_t v = __builtin_amdgcn_readlane(Sn.r[0], ln);
 #pragma unroll
-        for (int q = 1; q < NP; q++) v = (i == q) ? Sn.r[q] : v;
-        v = __builtin_amdgcn_readlane(v, ln);
-        return (d & 1) ? (v >> 16) : (v & 0xffffu);
+        for (int q = 1; q < NP; q++) {
+            const uint32_t w = __builtin_amdgcn_readlane(Sn.r[q], ln);
+            v = (e >> 1) == q ? w : v;
+        }
+        return (e & 1) ? (v >> 16) : (v & 0xffffu);
     };
     uint32_t nb = 0;
     if (best > 0 && best < D - 1) nb = fetch(best - 1) | (fetch(best + 1) << 16);
@@ -122,7 +138,8 @@ __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool ac
 
 struct Cursor {
     int xi, y;
-    int64_t off;  // element offset of pixel (xi, y) in a [H][W1][D] volume, kept incrementally
+    int64_t off;   // element offset of pixel (xi, y) in a [H][W1][D] volume, kept incrementally
+    int64_t woff;  // index of the pixel in the [H][W] WTA record image
 };
 
 // Band-boundary state written by the PATH_BOUNDARY pre-pass and read by k_sweep:
@@ -165,21 +182,26 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
         ld.xi = line;
     }
     ld.off = ((int64_t)ld.y * W1 + ld.xi) * D;
+    ld.woff = (int64_t)ld.y * g.W + g.minX1 + ld.xi;
     cp = ld;
     const int64_t step_off = ((int64_t)ry * W1 + rx) * D, row_off = (int64_t)W1 * D;
+    const int64_t step_w = (int64_t)ry * g.W + rx;
 
     auto advance = [&](Cursor &c) -> bool {  // returns true when the predecessor left the domain
         c.xi += rx;
         c.y += ry;
         c.off += step_off;
+        c.woff += step_w;
         if (c.xi >= W1) {
             c.xi = 0;
             c.off -= row_off;
+            c.woff -= W1;
             return true;
         }
         if (c.xi < 0) {
             c.xi = W1 - 1;
             c.off += row_off;
+            c.woff += W1;
             return true;
         }
         return false;
@@ -236,7 +258,7 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
                     }
                     if (MODE == PATH_LAST) {
                         const uint2 rec = wta_pixel<NP, PARTIAL>(Sn, lane, active, D, g.uniq);
-                        if (lane == 0) wta[(int64_t)cp.y * g.W + cp.xi + g.minX1] = rec;
+                        if (lane == 0) wta[cp.woff] = rec;
                     }
                 }
 

@@ -22,7 +22,8 @@ engs = {}
 for v in variants:
     e = cv.Engine(bench.sgbm_params(D, bs, mode))
     e.set_option(_lib.SGM_OPT_PROFILE, 1)
-    e.set_option(_lib.SGM_OPT_DEBUG, v)
+    e.set_option(_lib.SGM_OPT_DEBUG, v % 1000)       # variant = debug + 1000 * sweep rows
+    e.set_option(_lib.SGM_OPT_SWEEP_ROWS, v // 1000)
     engs[v] = e
 acc = {v: [] for v in variants}
 for rnd in range(6):
