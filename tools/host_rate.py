@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate through the host-pointer C ABI (numpy in, numpy out), 4K D=256 (GPU box)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import stereo_reconstruction_cv_amd as cv  # noqa: E402
+from stereo_reconstruction_cv_amd import synth  # noqa: E402
+
+H, W, D = 2160, 3840, 256
+l, r, _ = synth.make_pair(H, W, D, 1234)
+Q = synth.default_Q(W)
+for mode in (0, 1):
+    m = cv.StereoSGBM_create(**bench.sgbm_params(D, 7, mode))
+    m.compute(l, r)
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        d16 = m.compute(l, r)
+    t1 = time.perf_counter()
+    f = cv.get_engine(bench.sgbm_params(D, 7, mode)).disp_to_float_host(d16)
+    t2 = time.perf_counter()
+    xyz = cv.reprojectImageTo3D(f, Q)
+    t3 = time.perf_counter()
+    dt = (t1 - t0) / n
+    print(f"mode {mode}: host->host compute() {dt * 1e3:.1f} ms/pair = {H * W * D / dt / 1e6:.0f} Mdisp/s; "
+          f"disp_to_float {1e3 * (t2 - t1):.1f} ms; reprojectImageTo3D (99.5 MB back) {1e3 * (t3 - t2):.1f} ms")
