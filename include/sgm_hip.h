@@ -14,6 +14,8 @@
  *   sgm_filter_speckles  <- the two post-filters .compute() applies internally (upstream
  *                           medianBlur(disp,3) / filterSpeckles; cv2.medianBlur /
  *                           cv2.filterSpeckles are their public faces)        main.ipynb:664-665,668
+ *   sgm_compact_points   <- valid_points = points_3D[mask]; valid_colors = colors[mask]
+ *                           (ordered compaction + colour gather)                main.ipynb:726-737
  *   sgm_pipeline_device  <- cell c13: compute -> scale/mask -> reproject       main.ipynb:781,790
  *   sgm_compute_batch    <- the same, over N independent pairs (frame sharding unit)
  *
@@ -111,6 +113,9 @@ int sgm_disp_to_float(sgm_engine *e, const int16_t *disp, int64_t n, float *out)
 int sgm_reproject(sgm_engine *e, const float *disp, int H, int W, const double Q[16],
                   int handle_missing, float *xyz_out /* H*W*3 */);
 int sgm_valid_mask(sgm_engine *e, const float *xyz, const float *disp, int64_t n, uint8_t *mask);
+/* out_points: up to n*3 floats, out_colors (nullable, needs colors): up to n*3 bytes; *n_valid = rows written */
+int sgm_compact_points(sgm_engine *e, const float *xyz, const float *disp, const uint8_t *colors_rgb,
+                       int64_t n, float *out_points, uint8_t *out_colors, int64_t *n_valid);
 int sgm_median3x3(sgm_engine *e, const int16_t *src, int H, int W, int16_t *dst);
 int sgm_filter_speckles(sgm_engine *e, int16_t *img /* in place */, int H, int W, int newVal,
                         int maxSpeckleSize, int maxDiff);
@@ -124,6 +129,10 @@ int sgm_reproject_device(sgm_engine *e, const void *d_disp_f32, int H, int W, co
                          int handle_missing, void *d_xyz_f32);
 int sgm_valid_mask_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f32, int64_t n,
                           void *d_mask_u8);
+/* device buffers sized for the worst case (n points); blocks until the count is known */
+int sgm_compact_points_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f32,
+                              const void *d_colors_rgb, int64_t n, void *d_out_points,
+                              void *d_out_colors, int64_t *n_valid);
 /* cell c13 in one call: disparity (int16) -> float disparity -> XYZ; any output may be NULL */
 int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W,
                         int64_t stride_bytes, const double Q[16], void *d_disp_i16,

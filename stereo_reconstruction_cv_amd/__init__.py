@@ -7,10 +7,11 @@ from .stereo import (CV_32F, STEREO_SGBM_MODE_HH, STEREO_SGBM_MODE_HH4, STEREO_S
                      STEREO_SGBM_MODE_SGBM_3WAY, Engine, StereoSGBM, StereoSGBM_create, clear_engine_cache, error,
                      get_device, get_engine, reprojectImageTo3D, set_device)
 from .pipeline import compute_disparity_map, reconstruct_3D, run_disparity, valid_point_mask
+from .pointcloud import read_point_cloud, valid_points, write_point_cloud
 
 __all__ = [
     "StereoSGBM_create", "StereoSGBM", "reprojectImageTo3D", "error", "Engine", "get_engine", "set_device",
     "get_device", "clear_engine_cache", "compute_disparity_map", "reconstruct_3D", "valid_point_mask",
-    "run_disparity", "STEREO_SGBM_MODE_SGBM", "STEREO_SGBM_MODE_HH", "STEREO_SGBM_MODE_SGBM_3WAY",
+    "run_disparity", "valid_points", "write_point_cloud", "read_point_cloud", "STEREO_SGBM_MODE_SGBM", "STEREO_SGBM_MODE_HH", "STEREO_SGBM_MODE_SGBM_3WAY",
     "STEREO_SGBM_MODE_HH4", "CV_32F",
 ]

@@ -304,4 +304,80 @@ __global__ __launch_bounds__(256) void k_valid_mask(const float *__restrict__ xy
     mask[i] = (uint8_t)(!isnan(X) && !isinf(X) && disp[i] > 0.0f);
 }
 
+// ------------------------------------------------------------------------------------------
+// Valid-point compaction + colour gather (/root/reference/main.ipynb:726-737):
+//   mask = ~isnan(X) & ~isinf(X) & (disp > 0);  valid_points = points_3D[mask];  valid_colors = colors[mask]
+// numpy boolean indexing keeps row-major order, so the compaction is an ordered one:
+// per-256-pixel block counts -> exclusive scan -> ordered scatter (ballot + popcount inside a wave).
+__device__ __forceinline__ bool point_valid(const float *xyz, const float *disp, int64_t i)
+{
+    const float X = xyz[i * 3];
+    return !isnan(X) && !isinf(X) && disp[i] > 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_compact_count(const float *__restrict__ xyz, const float *__restrict__ disp,
+                                                       int64_t n, uint32_t *__restrict__ counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < n && point_valid(xyz, disp, i);
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(v);
+    __shared__ uint32_t wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__builtin_popcountll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of `m` block counts by one workgroup (m is a few 10^4 at most); total -> counts[m]
+__global__ __launch_bounds__(1024) void k_compact_scan(uint32_t *counts, int m)
+{
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (m + 1023) / 1024;
+    const int lo = min(t * per, m), hi = min(lo + per, m);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan of the partials
+        const uint32_t v = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0u;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t c = counts[i];
+        counts[i] = run;
+        run += c;
+    }
+    if (t == 1023) counts[m] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_compact_scatter(const float *__restrict__ xyz, const float *__restrict__ disp,
+                                                         const uint8_t *__restrict__ colors, int64_t n,
+                                                         const uint32_t *__restrict__ offsets,
+                                                         float *__restrict__ out_xyz, uint8_t *__restrict__ out_rgb)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < n && point_valid(xyz, disp, i);
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(v);
+    __shared__ uint32_t wsum[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wsum[w] = (uint32_t)__builtin_popcountll(b);
+    __syncthreads();
+    uint32_t base = offsets[blockIdx.x];
+    for (int k = 0; k < w; k++) base += wsum[k];
+    if (v) {
+        const uint32_t o = base + (uint32_t)__builtin_popcountll(b & ((1ull << lane) - 1ull));
+        out_xyz[(int64_t)o * 3 + 0] = xyz[i * 3 + 0];
+        out_xyz[(int64_t)o * 3 + 1] = xyz[i * 3 + 1];
+        out_xyz[(int64_t)o * 3 + 2] = xyz[i * 3 + 2];
+        if (colors) {
+            out_rgb[(int64_t)o * 3 + 0] = colors[i * 3 + 0];
+            out_rgb[(int64_t)o * 3 + 1] = colors[i * 3 + 1];
+            out_rgb[(int64_t)o * 3 + 2] = colors[i * 3 + 2];
+        }
+    }
+}
+
 }  // namespace sgm

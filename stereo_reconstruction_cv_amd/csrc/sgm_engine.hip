@@ -94,6 +94,7 @@ struct sgm_engine {
     DevBuf disp_raw, disp_med, disp_out;  // int16 [H][W]
     DevBuf label, csize, rlen;          // int32 [H][W] each
     DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
+    DevBuf ccount, cpts, crgb, crgb_in; // point compaction
 
     // profiling
     std::vector<hipEvent_t> events;
@@ -595,7 +596,7 @@ void sgm_destroy(sgm_engine *e)
     (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta, &e->bndL, &e->bndL2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
-                      &e->minkey};
+                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->aux) {
@@ -767,6 +768,54 @@ int sgm_valid_mask(sgm_engine *e, const float *xyz, const float *disp, int64_t n
     HIP_TRY(hipMemcpyAsync(e->xyz.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
     if ((rc = sgm_valid_mask_device(e, e->xyz.p, e->f32.p, n, e->mask.p))) return rc;
     HIP_TRY(hipMemcpyAsync(mask, e->mask.p, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_compact_points_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f32, const void *d_colors_rgb,
+                              int64_t n, void *d_out_points, void *d_out_colors, int64_t *n_valid)
+{
+    if (!e || !d_xyz || !d_disp_f32 || !d_out_points || !n_valid || n <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (d_out_colors && !d_colors_rgb) return set_err(SGM_ERR_INVALID_ARG, "out_colors requested without colors");
+    if (n >= (1ll << 32)) return set_err(SGM_ERR_UNSUPPORTED, "more than 2^32 points");
+    HIP_TRY(hipSetDevice(e->device));
+    const int m = (int)((n + 255) / 256);
+    int rc;
+    if ((rc = e->ccount.ensure((size_t)(m + 1) * 4))) return rc;
+    uint32_t *cnt = (uint32_t *)e->ccount.p;
+    hipStream_t st = e->stream;
+    hipLaunchKernelGGL(k_compact_count, dim3(m), dim3(256), 0, st, (const float *)d_xyz, (const float *)d_disp_f32, n, cnt);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, cnt, m);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(m), dim3(256), 0, st, (const float *)d_xyz, (const float *)d_disp_f32,
+                       (const uint8_t *)(d_out_colors ? d_colors_rgb : nullptr), n, (const uint32_t *)cnt,
+                       (float *)d_out_points, (uint8_t *)d_out_colors);
+    KCHECK();
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, cnt + m, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_valid = (int64_t)total;
+    return SGM_OK;
+}
+
+int sgm_compact_points(sgm_engine *e, const float *xyz, const float *disp, const uint8_t *colors_rgb, int64_t n,
+                       float *out_points, uint8_t *out_colors, int64_t *n_valid)
+{
+    if (!e || !xyz || !disp || !out_points || !n_valid || n <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (out_colors && !colors_rgb) return set_err(SGM_ERR_INVALID_ARG, "out_colors requested without colors");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->f32.ensure((size_t)n * 4)) || (rc = e->xyz.ensure((size_t)n * 12)) || (rc = e->cpts.ensure((size_t)n * 12))) return rc;
+    if (out_colors && ((rc = e->crgb_in.ensure((size_t)n * 3)) || (rc = e->crgb.ensure((size_t)n * 3)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->f32.p, disp, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->xyz.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
+    if (out_colors) HIP_TRY(hipMemcpyAsync(e->crgb_in.p, colors_rgb, (size_t)n * 3, hipMemcpyHostToDevice, e->stream));
+    if ((rc = sgm_compact_points_device(e, e->xyz.p, e->f32.p, out_colors ? e->crgb_in.p : nullptr, n, e->cpts.p,
+                                        out_colors ? e->crgb.p : nullptr, n_valid)))
+        return rc;
+    if (*n_valid > 0) {
+        HIP_TRY(hipMemcpyAsync(out_points, e->cpts.p, (size_t)*n_valid * 12, hipMemcpyDeviceToHost, e->stream));
+        if (out_colors) HIP_TRY(hipMemcpyAsync(out_colors, e->crgb.p, (size_t)*n_valid * 3, hipMemcpyDeviceToHost, e->stream));
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     return SGM_OK;
 }

@@ -143,6 +143,23 @@ class Engine:
                                      out.ctypes.data))
         return out
 
+    def compact_points_host(self, xyz: np.ndarray, disp: np.ndarray, colors: np.ndarray | None = None):
+        """(points_3D[mask], colors[mask]) with the mask of main.ipynb:726-730, row-major order kept."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        disp = np.ascontiguousarray(disp, np.float32).reshape(-1)
+        n = disp.size
+        pts = np.empty((n, 3), np.float32)
+        rgb = None
+        cp = None
+        if colors is not None:
+            colors = np.ascontiguousarray(colors, np.uint8).reshape(-1, 3)
+            rgb = np.empty((n, 3), np.uint8)
+            cp = colors.ctypes.data
+        nv = C.c_int64(0)
+        _check(self._L.sgm_compact_points(self._h, xyz.ctypes.data, disp.ctypes.data, cp, n, pts.ctypes.data,
+                                          rgb.ctypes.data if rgb is not None else None, C.byref(nv)))
+        return (pts[:nv.value].copy(), rgb[:nv.value].copy() if rgb is not None else None)
+
     def median3x3_host(self, img: np.ndarray) -> np.ndarray:
         img = np.ascontiguousarray(img, np.int16)
         out = np.empty_like(img)
