@@ -30,12 +30,21 @@ enum { PATH_FIRST = 0, PATH_ACCUM = 1, PATH_LAST = 2, PATH_BOUNDARY = 3 };
 // is what S accumulates, and the per-lane partial minimum (both int16 halves) for the caller to
 // reduce -- alone (wave_min_pk) or batched with other directions.  Idle lanes of a partial wave
 // hold the MAX_COST sentinel.
+// Persistent "fill" registers of the two DPP wave shifts of one direction: lane 0 of `up` and
+// lane 63 of `dn` never receive data from a neighbour, so they keep the MAX_COST sentinel they
+// were initialised with for the whole kernel; tying the shift's `old` operand to the previous
+// value of the same variable lets hipcc emit the bare v_mov_b32_dpp without a refill.
+struct ShiftRegs {
+    uint32_t up = SGM_SENT, dn = SGM_SENT;
+};
+
 template <int NP, bool PARTIAL>
 __device__ __forceinline__ void path_elem(const Pack<NP> &Cp, const Pack<NP> &Lq, uint32_t P1s, uint32_t P2s,
-                                          bool active, Pack<NP> &Ln, uint32_t &rmin)
+                                          bool active, Pack<NP> &Ln, uint32_t &rmin, ShiftRegs &sr)
 {
-    const uint32_t up = from_lower_lane(Lq.r[NP - 1], SGM_SENT);
-    const uint32_t dn = from_upper_lane(Lq.r[0], SGM_SENT);
+    sr.up = from_lower_lane(Lq.r[NP - 1], sr.up);
+    sr.dn = from_upper_lane(Lq.r[0], sr.dn);
+    const uint32_t up = sr.up, dn = sr.dn;
     rmin = SGM_SENT;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
 
     Pack<NP> L;  // normalised state L_r(q,.) - min (all-zero when q is outside the domain)
     L.fill(init);
+    ShiftRegs sr;
 
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
     constexpr bool READS_S = (MODE == PATH_ACCUM || MODE == PATH_LAST);
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
             if (full || step0 + k < nsteps) {
                 Pack<NP> Ln, Lnorm;
                 uint32_t rmin;
-                path_elem<NP, PARTIAL>(cb[k], L, P1s, P2s, active, Ln, rmin);
+                path_elem<NP, PARTIAL>(cb[k], L, P1s, P2s, active, Ln, rmin, sr);
                 path_normalise<NP, PARTIAL>(Ln, halves_min(wave_min_pk(rmin)), active, Lnorm);
 
                 if (MODE == PATH_BOUNDARY) {
@@ -317,6 +327,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
     Pack<NP> L[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) L[d].fill(init);
+    ShiftRegs sr[3];
     Pack<NP> cA[PB][3], cB[PB][3];
 
     // does role d stay inside [0, W1) for the PB steps starting at column x ?
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
         Pack<NP> N[3];
         uint32_t r[3];
 #pragma unroll
-        for (int d = 0; d < 3; d++) path_elem<NP, PARTIAL>(c3[d], L[d], P1s, P2s, active, N[d], r[d]);
+        for (int d = 0; d < 3; d++) path_elem<NP, PARTIAL>(c3[d], L[d], P1s, P2s, active, N[d], r[d], sr[d]);
         const uint32_t m01 = wave_min_pk(pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])));
         const uint32_t m2 = halves_min(wave_min_pk(r[2]));
         path_normalise<NP, PARTIAL>(N[0], m01 & 0xffffu, active, L[0]);

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
 
     Pack<NP> L0;  // normalised state of the in-row path
     L0.fill(init);
+    ShiftRegs sr0, srA, srB, srC;
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
     // element offset of pixel k of this row: e0 + k * ek (32-bit inside the row)
     const int16_t *const Crow = a.C + (int64_t)y * W1 * D;
@@ -211,10 +212,10 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
                      const Pack<NP> &QC, int u, int k) {
         Pack<NP> N0, NA, NB, NC;
         uint32_t r0, rA, rB, rC;
-        path_elem<NP, PARTIAL>(Cp, L0, P1s, P2s, active, N0, r0);
-        path_elem<NP, PARTIAL>(Cp, QA, P1s, P2s, active, NA, rA);
-        path_elem<NP, PARTIAL>(Cp, QB, P1s, P2s, active, NB, rB);
-        path_elem<NP, PARTIAL>(Cp, QC, P1s, P2s, active, NC, rC);
+        path_elem<NP, PARTIAL>(Cp, L0, P1s, P2s, active, N0, r0, sr0);
+        path_elem<NP, PARTIAL>(Cp, QA, P1s, P2s, active, NA, rA, srA);
+        path_elem<NP, PARTIAL>(Cp, QB, P1s, P2s, active, NB, rB, srB);
+        path_elem<NP, PARTIAL>(Cp, QC, P1s, P2s, active, NC, rC, srC);
         const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));  // {min 0, min A}
         const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));  // {min B, min C}
         Pack<NP> LA, LB, LC;

@@ -17,6 +17,7 @@ __global__ void k(uint32_t *out, unsigned long long *cyc, int iters, uint32_t se
     Q1 = L; Q2 = C; Q3 = L;
     const uint32_t P1s = splat16(100), P2s = splat16(3000);
     uint32_t acc = 0;
+    ShiftRegs s0, s1, s2, s3;
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
         if (PAT == 0) {  // 16 dependent packed mins
@@ -29,19 +30,19 @@ __global__ void k(uint32_t *out, unsigned long long *cyc, int iters, uint32_t se
             L.r[0] = pk_add(N.r[0], C.r[0]); L.r[1] = pk_add(N.r[1], C.r[1]);
         } else if (PAT == 2) {  // one direction element-wise only (no reduce)
             Pack<2> N; uint32_t r;
-            path_elem<2, false>(C, L, P1s, P2s, true, N, r);
+            path_elem<2, false>(C, L, P1s, P2s, true, N, r, s0);
             L = N; acc ^= r;
         } else if (PAT == 3) {  // one full direction step (k_path body)
             Pack<2> N, Nn; uint32_t r;
-            path_elem<2, false>(C, L, P1s, P2s, true, N, r);
+            path_elem<2, false>(C, L, P1s, P2s, true, N, r, s0);
             path_normalise<2, false>(N, halves_min(wave_min_pk(r)), true, Nn);
             L = Nn;
         } else if (PAT == 4) {  // sweep pixel: 4 directions, 2 batched reductions
             Pack<2> N0, NA, NB, NC; uint32_t r0, rA, rB, rC;
-            path_elem<2, false>(C, L, P1s, P2s, true, N0, r0);
-            path_elem<2, false>(C, Q1, P1s, P2s, true, NA, rA);
-            path_elem<2, false>(C, Q2, P1s, P2s, true, NB, rB);
-            path_elem<2, false>(C, Q3, P1s, P2s, true, NC, rC);
+            path_elem<2, false>(C, L, P1s, P2s, true, N0, r0, s0);
+            path_elem<2, false>(C, Q1, P1s, P2s, true, NA, rA, s1);
+            path_elem<2, false>(C, Q2, P1s, P2s, true, NB, rB, s2);
+            path_elem<2, false>(C, Q3, P1s, P2s, true, NC, rC, s3);
             const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));
             const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));
             path_normalise<2, false>(N0, m0A & 0xffffu, true, L);
