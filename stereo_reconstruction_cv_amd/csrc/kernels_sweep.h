@@ -34,6 +34,7 @@ struct SweepArgs {
     const int16_t *bndL;  // [band][x][3 roles][D], normalised
     uint2 *wta;
     int keepS;
+    int dbg;  // timing experiments only (results become wrong): 64 = loader wave skips its HBM loads
 };
 
 constexpr int SWEEP_MAX_ROWS = 9;  // compute waves per workgroup (640 threads -> 168 VGPRs per lane)
@@ -104,59 +105,129 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
 
     if (wave == R) {
         // ==== loader wave: boundary state HBM -> registers -> LDS, 2 steps ahead of wave 0 ====
-        const bool has_prev = band > 0;
+        const bool has_prev = band > 0 && !(a.dbg & 64);
         Pack<NP> bA[PB][3], bB[PB][3];
-        auto xof = [&](int k) { return a.xdir > 0 ? k : W1 - 1 - k; };
-        auto lb = [&](Pack<NP>(*b)[3], int k0) {
-            if (!has_prev) return;
+        // this band's boundary row as a buffer resource: [x][3 roles][D] int16
+        const int row_bytes = W1 * 3 * D * 2;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.bndL + (int64_t)band * W1 * 3 * D), 0, row_bytes, 0x00020000);
+        const int voff = lane_off * 2;
+        const int px_bytes = 3 * D * 2;
+        const int pk = a.xdir > 0 ? px_bytes : -px_bytes;           // byte step per pixel of the sweep order
+        const int p0 = a.xdir > 0 ? 0 : (W1 - 1) * px_bytes;
+        // FULL = every pixel of the block exists: no guards, so hipcc can count the loads in flight
+        // (with a branch between issue and use it falls back to vmcnt(0) and the whole lockstep
+        // workgroup waits for HBM latency every block)
+        auto lb_t = [&](auto full_c, Pack<NP>(*b)[3], int k0) {
+            constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
             for (int u = 0; u < PB; u++) {
-                if (k0 + u < W1) {
-                    const int64_t px = (int64_t)band * W1 + xof(k0 + u);
+                if (FULL || k0 + u < W1) {
+                    const int so = p0 + (k0 + u) * pk;
 #pragma unroll
-                    for (int d = 0; d < 3; d++) b[u][d].load(a.bndL + (px * 3 + d) * D + lane_off);
+                    for (int d = 0; d < 3; d++) buf_load<NP>(b[u][d], rsrc, voff, so + d * D * 2);
                 }
             }
         };
-        auto wb = [&](Pack<NP>(*b)[3], int u, int k) {  // pixel k, k % PB == u
-            if (k > W1) return;
+        auto wb_t = [&](auto full_c, Pack<NP>(*b)[3], int u, int k) {  // pixel k, k % PB == u
+            constexpr bool FULL = decltype(full_c)::value;
+            if (!FULL && k > W1) return;
             uint32_t *slot = ring0 + u * SLOT;
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 Pack<NP> v;
-                if (has_prev && k < W1) {
+                if (FULL || k < W1) {
                     v = b[u][d];
                     if (PARTIAL && !active) v.fill(SGM_SENT);
                 } else {
-                    v.fill(init);  // first band of the sweep, or the virtual pixel W1
+                    v.fill(init);  // the virtual pixel W1
                 }
                 lds_store<NP>(v, slot + d * ROLE);
             }
         };
-        int t = 0;
-        auto step_group = [&](Pack<NP>(*b)[3], int u0, int kbase) {  // PPS pixels, then the step barrier
-            if (t < T) {
+        int t = 0;  // lockstep steps done; step t writes pixels PPS*(t+2) .. PPS*(t+2)+PPS-1
+        if (!has_prev) {
+            // first band of the sweep: the row above is the all-zero start state everywhere
 #pragma unroll
-                for (int p = 0; p < PPS; p++) wb(b, u0 + p, kbase + u0 + p);
+            for (int u = 0; u < RING; u++) write_start_state(ring0, u);
+            wg_barrier();
+            for (; t < T; t++) wg_barrier();
+            return;
+        }
+        write_start_state(ring0, RING - 1);
+        const std::true_type full{};
+        const std::false_type part{};
+        // prologue: pixels 0 .. 2*PPS-1, then the rest of block 0
+        if (2 * PB <= W1) {
+            lb_t(full, bA, 0);
+            lb_t(full, bB, PB);
+#pragma unroll
+            for (int p = 0; p < 2 * PPS; p++) wb_t(full, bA, p, p);
+            wg_barrier();
+#pragma unroll
+            for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) {
+#pragma unroll
+                for (int p = 0; p < PPS; p++) wb_t(full, bA, u0 + p, u0 + p);
                 wg_barrier();
                 t++;
             }
-        };
-        lb(bA, 0);
-        lb(bB, PB);
-        write_start_state(ring0, RING - 1);
+        } else {
+            lb_t(part, bA, 0);
+            lb_t(part, bB, PB);
 #pragma unroll
-        for (int p = 0; p < 2 * PPS; p++) wb(bA, p, p);
-        wg_barrier();  // prologue barrier: the first two steps' worth of pixels is in place
+            for (int p = 0; p < 2 * PPS; p++) wb_t(part, bA, p, p);
+            wg_barrier();
 #pragma unroll
-        for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) step_group(bA, u0, 0);
-        for (int k0 = PB; t < T; k0 += 2 * PB) {
-            lb(bA, k0 + PB);
+            for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) {
+                if (t < T) {
 #pragma unroll
-            for (int u0 = 0; u0 < PB; u0 += PPS) step_group(bB, u0, k0);
-            lb(bB, k0 + 2 * PB);
+                    for (int p = 0; p < PPS; p++) wb_t(part, bA, u0 + p, u0 + p);
+                    wg_barrier();
+                    t++;
+                }
+            }
+        }
+        int k0 = PB;  // bB holds block [k0, k0+PB), bA is free
+        // steady state: blocks k0 (in bB), k0+PB (to bA), k0+2PB (to bB) all full -> straight-line
+        for (; k0 + 3 * PB <= W1; k0 += 2 * PB) {
+            lb_t(full, bA, k0 + PB);
 #pragma unroll
-            for (int u0 = 0; u0 < PB; u0 += PPS) step_group(bA, u0, k0 + PB);
+            for (int u0 = 0; u0 < PB; u0 += PPS) {
+#pragma unroll
+                for (int p = 0; p < PPS; p++) wb_t(full, bB, u0 + p, k0 + u0 + p);
+                wg_barrier();
+            }
+            lb_t(full, bB, k0 + 2 * PB);
+#pragma unroll
+            for (int u0 = 0; u0 < PB; u0 += PPS) {
+#pragma unroll
+                for (int p = 0; p < PPS; p++) wb_t(full, bA, u0 + p, k0 + PB + u0 + p);
+                wg_barrier();
+            }
+            t += 2 * (PB / PPS);
+        }
+        // tail: guarded blocks, then idle steps until every row has finished
+        for (; t < T; k0 += 2 * PB) {
+            lb_t(part, bA, k0 + PB);
+#pragma unroll
+            for (int u0 = 0; u0 < PB; u0 += PPS) {
+                if (t < T) {
+#pragma unroll
+                    for (int p = 0; p < PPS; p++) wb_t(part, bB, u0 + p, k0 + u0 + p);
+                    wg_barrier();
+                    t++;
+                }
+            }
+            lb_t(part, bB, k0 + 2 * PB);
+#pragma unroll
+            for (int u0 = 0; u0 < PB; u0 += PPS) {
+                if (t < T) {
+#pragma unroll
+                    for (int p = 0; p < PPS; p++) wb_t(part, bA, u0 + p, k0 + PB + u0 + p);
+                    wg_barrier();
+                    t++;
+                }
+            }
         }
         return;
     }
@@ -181,11 +252,16 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     L0.fill(init);
     ShiftRegs sr0, srA, srB, srC;
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
-    // element offset of pixel k of this row: e0 + k * ek (32-bit inside the row)
-    const int16_t *const Crow = a.C + (int64_t)y * W1 * D;
-    int16_t *const Srow = a.S + (int64_t)y * W1 * D;
-    const int ek = a.xdir > 0 ? D : -D;
-    const int e0 = (a.xdir > 0 ? 0 : (W1 - 1) * D) + lane_off;
+    // this row of C and S as buffer resources: one constant per-lane byte offset register plus a
+    // scalar byte offset per pixel (b0 + k * bk), so no address VGPRs alias the load destinations
+    const int row_bytes = W1 * D * 2;
+    const __amdgpu_buffer_rsrc_t Crow = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.C + (int64_t)y * W1 * D), 0, row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Srow = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.S + (int64_t)y * W1 * D), 0, row_bytes, 0x00020000);
+    const int voff = lane_off * 2;
+    const int bk = a.xdir > 0 ? D * 2 : -D * 2;
+    const int b0 = a.xdir > 0 ? 0 : (W1 - 1) * D * 2;
     const int wk = a.xdir > 0 ? 1 : -1;
     uint2 *const wrow = a.wta + (int64_t)y * g.W + g.minX1 + (a.xdir > 0 ? 0 : W1 - 1);
 
@@ -196,17 +272,12 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
 #pragma unroll
         for (int u = 0; u < PB; u++) {
             if (FULL || k0 + u < W1) {
-                const int e = e0 + (k0 + u) * ek;
-                cb[u].load(Crow + e);
-                if (READS_S) sb[u].load(Srow + e);
+                const int so = b0 + (k0 + u) * bk;
+                buf_load<NP>(cb[u], Crow, voff, so);
+                if (READS_S) buf_load<NP>(sb[u], Srow, voff, so);
             }
         }
     };
-    auto load_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {
-        if (k0 + PB <= W1) load_block_t(std::true_type{}, cb, sb, k0);
-        else load_block_t(std::false_type{}, cb, sb, k0);
-    };
-
     // one pixel: four recurrences (minima reduced two directions at a time), hand-off, S, WTA
     auto pixel = [&](const Pack<NP> &Cp, const Pack<NP> &Sp, const Pack<NP> &QA, const Pack<NP> &QB,
                      const Pack<NP> &QC, int u, int k) {
@@ -235,7 +306,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
             Sn.r[i] = v;
         }
         if (MODE != SWEEP_LAST || a.keepS) {
-            if (active) Sn.store(Srow + e0 + k * ek);
+            if (active) buf_store<NP>(Sn, Srow, voff, b0 + k * bk);
         }
         if (MODE == SWEEP_LAST) {
             const uint2 rec = wta_pixel<NP, PARTIAL>(Sn, lane, active, D, g.uniq);
@@ -266,17 +337,26 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
             }
         }
     };
-    auto compute_block = [&](Pack<NP> *cb, Pack<NP> *sb, int k0) {
-        if (k0 + PB <= W1) compute_block_t(std::true_type{}, cb, sb, k0);
-        else compute_block_t(std::false_type{}, cb, sb, k0);
-    };
-
-    load_block(cA, sA, 0);
-    for (int k0 = 0; k0 < W1; k0 += 2 * PB) {
-        load_block(cB, sB, k0 + PB);
-        compute_block(cA, sA, k0);
-        load_block(cA, sA, k0 + 2 * PB);
-        compute_block(cB, sB, k0 + PB);
+    {
+        const std::true_type full{};
+        const std::false_type part{};
+        int k0 = 0;
+        if (PB <= W1) load_block_t(full, cA, sA, 0);
+        else load_block_t(part, cA, sA, 0);
+        // steady state: blocks k0 (in cA), k0+PB (to cB), k0+2PB (to cA) all full -> one straight-line
+        // iteration, so the loads of the next block stay in flight across the current block
+        for (; k0 + 3 * PB <= W1; k0 += 2 * PB) {
+            load_block_t(full, cB, sB, k0 + PB);
+            compute_block_t(full, cA, sA, k0);
+            load_block_t(full, cA, sA, k0 + 2 * PB);
+            compute_block_t(full, cB, sB, k0 + PB);
+        }
+        for (; k0 < W1; k0 += 2 * PB) {  // tail: guarded
+            load_block_t(part, cB, sB, k0 + PB);
+            compute_block_t(part, cA, sA, k0);
+            load_block_t(part, cA, sA, k0 + 2 * PB);
+            compute_block_t(part, cB, sB, k0 + PB);
+        }
     }
     // one step after the last real pixel: the virtual pixel W1 (start state) for the row below
     if (wave < R - 1) {

@@ -118,6 +118,50 @@ template <int NP> struct Pack {
     }
 };
 
+
+// Buffer (SRSRC) loads: one wave-uniform descriptor + one per-lane 32-bit offset register that
+// never changes + a scalar byte offset per access.  Used where many loads are issued back to back
+// (the sweep's loader wave): with flat/global addressing hipcc gave every access its own VGPR
+// offset, reused those registers as load destinations and had to drain vmcnt(0) inside the burst.
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ void buf_load(Pack<NP> &p, __amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes)
+{
+    if constexpr (NP == 1) {
+        p.r[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, 0);
+    } else if constexpr (NP == 2) {
+        const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bytes, soff_bytes, 0);
+        p.r[0] = v.x;
+        p.r[1] = v.y;
+    } else {
+        const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 0);
+        p.r[0] = v.x;
+        p.r[1] = v.y;
+        p.r[2] = v.z;
+        p.r[3] = v.w;
+    }
+}
+template <int NP>
+__device__ __forceinline__ void buf_store(const Pack<NP> &p, __amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes)
+{
+    if constexpr (NP == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(p.r[0], rsrc, voff_bytes, soff_bytes, 0);
+    } else if constexpr (NP == 2) {
+        v2u32 v;
+        v.x = p.r[0];
+        v.y = p.r[1];
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff_bytes, soff_bytes, 0);
+    } else {
+        v4u32 v;
+        v.x = p.r[0];
+        v.y = p.r[1];
+        v.z = p.r[2];
+        v.w = p.r[3];
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff_bytes, soff_bytes, 0);
+    }
+}
+
 #define SGM_MAX_COST 32767
 #define SGM_SENT 0x7fff7fffu  // packed pair of MAX_COST
 

@@ -14,7 +14,7 @@ from stereo_reconstruction_cv_amd import _lib, synth  # noqa: E402
 
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "16"])]
-H, W, D, bs = 2160, 3840, 256, 7
+H, W, D, bs = int(os.environ.get('AB_H', 2160)), int(os.environ.get('AB_W', 3840)), int(os.environ.get('AB_D', 256)), 7
 l, r, _ = synth.make_pair(H, W, D, 1234)
 dl, dr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
 out = torch.empty((H, W), dtype=torch.int16, device="cuda")
