@@ -290,18 +290,19 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
 // ------------------------------------------------------------------------------------------
 // Boundary pre-pass for k_sweep, all three roles in one wave: line `blockIdx.x` of each of the
 // directions (rx = +xdir, 0, -xdir; ry = ydir) is advanced together, one image row per step.
-// Three independent dependency chains per wave (the scheduler interleaves them) and the three
-// reads of a cost row land close together in time, so two of them can be served by L2 / MALL.
-// Only the normalised state at band boundaries is stored (Boundary layout above).
+// Three independent dependency chains per wave (the scheduler interleaves them).  Only the
+// normalised state at band boundaries is stored (Boundary layout above).
 //
-// Blocks of PB rows in which no diagonal leaves the image run as straight-line code (constant
-// address strides, no cursor arithmetic); the rare blocks with a wrap take the per-step path.
-// Offsets are 32-bit element indices (the host checks H * W1 * D < 2^31).
+// Prefetch discipline (see kernels_sweep.h): the cost volume is one buffer resource, every load
+// is "constant per-lane offset register + scalar byte offset", and an iteration of two blocks
+// in which no diagonal leaves the image is straight-line code, so hipcc keeps the next block's
+// loads in flight (counted vmcnt).  The rare iterations with a wrap take the per-step path.
+// Byte offsets are 32-bit (the host checks volume bytes < 2^32).
 template <int NP, bool PARTIAL>
 __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
                                                  int16_t *__restrict__ bndL, int R)
 {
-    constexpr int PB = NP == 4 ? 4 : 8;
+    constexpr int PB = 4;  // rows per prefetch block: 2 blocks x 3 roles in registers keeps 4 waves per SIMD
     const int lane = threadIdx.x;
     const int line = blockIdx.x;
     const int W1 = g.W1, D = g.D, H = g.H;
@@ -310,19 +311,22 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     const uint32_t init = active ? 0u : SGM_SENT;
     const int rx[3] = {xdir, 0, -xdir};
-    const int row_off = W1 * D;
-    int stride[3];  // element stride of one step of each role
+    const uint32_t row_bytes = (uint32_t)W1 * D * 2;
+    const __amdgpu_buffer_rsrc_t Cbuf =
+        __builtin_amdgcn_make_buffer_rsrc((void *)C, 0, (int)(row_bytes * (uint32_t)H), 0x00020000);
+    const int voff = lane_off * 2;
+    uint32_t stride[3];  // byte stride of one step of each role (two's complement for negative steps)
 #pragma unroll
-    for (int d = 0; d < 3; d++) stride[d] = ydir * row_off + rx[d] * D;
-    const int16_t *const Cl = C + lane_off;
+    for (int d = 0; d < 3; d++) stride[d] = (uint32_t)(ydir * (int)row_bytes + rx[d] * D * 2);
 
-    // per role: column and element offset of the next pixel of the load / compute cursors
-    int xl[3], xc[3], offl[3];
+    // per role: column of the next pixel of the load / compute cursors, byte offset of the load cursor
+    int xl[3], xc[3];
+    uint32_t offl[3];
     const int y0 = ydir > 0 ? 0 : H - 1;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         xl[d] = xc[d] = line;
-        offl[d] = (y0 * W1 + line) * D;
+        offl[d] = ((uint32_t)y0 * W1 + line) * D * 2;
     }
     Pack<NP> L[3];
 #pragma unroll
@@ -330,54 +334,55 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
     ShiftRegs sr[3];
     Pack<NP> cA[PB][3], cB[PB][3];
 
-    // does role d stay inside [0, W1) for the PB steps starting at column x ?
-    auto stays = [&](int x, int d) { const int xe = x + (PB - 1) * rx[d]; return xe >= 0 && xe < W1; };
-
-    auto load_block = [&](Pack<NP>(*cb)[3], int step0) {
-        if (step0 >= H) return;
-        if (step0 + PB <= H && stays(xl[0], 0) && stays(xl[2], 2)) {
-#pragma unroll
-            for (int k = 0; k < PB; k++)
-#pragma unroll
-                for (int d = 0; d < 3; d++) cb[k][d].load(Cl + (offl[d] + k * stride[d]));
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                xl[d] += PB * rx[d];
-                offl[d] += PB * stride[d];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PB; k++) {
-                if (step0 + k < H) {
-#pragma unroll
-                    for (int d = 0; d < 3; d++) {
-                        cb[k][d].load(Cl + offl[d]);
-                        xl[d] += rx[d];
-                        offl[d] += stride[d];
-                    }
-                }
-                // a column index that left the image re-enters on the other side (next row)
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    if (xl[d] >= W1) {
-                        xl[d] -= W1;
-                        offl[d] -= row_off;
-                    } else if (xl[d] < 0) {
-                        xl[d] += W1;
-                        offl[d] += row_off;
-                    }
-                }
-            }
-        }
-        // normalise a cursor that stands exactly one past the border after a straight block
+    // does a diagonal that stands at column x stay inside [0, W1) for the next n steps ?
+    auto stays = [&](int x, int d, int n) { const int xe = x + (n - 1) * rx[d]; return xe >= 0 && xe < W1; };
+    auto wrap_load = [&]() {
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             if (xl[d] >= W1) {
                 xl[d] -= W1;
-                offl[d] -= row_off;
+                offl[d] -= row_bytes;
             } else if (xl[d] < 0) {
                 xl[d] += W1;
-                offl[d] += row_off;
+                offl[d] += row_bytes;
+            }
+        }
+    };
+    auto wrap_compute = [&]() {  // a line that left the image restarts from the zero state
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if (xc[d] >= W1) {
+                xc[d] = 0;
+                L[d].fill(init);
+            } else if (xc[d] < 0) {
+                xc[d] = W1 - 1;
+                L[d].fill(init);
+            }
+        }
+    };
+
+    auto load_fast = [&](Pack<NP>(*cb)[3]) {  // PB rows, no wrap inside
+#pragma unroll
+        for (int k = 0; k < PB; k++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) buf_load<NP>(cb[k][d], Cbuf, voff, (int)(offl[d] + (uint32_t)k * stride[d]));
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            xl[d] += PB * rx[d];
+            offl[d] += (uint32_t)PB * stride[d];
+        }
+    };
+    auto load_slow = [&](Pack<NP>(*cb)[3], int step0) {
+#pragma unroll
+        for (int k = 0; k < PB; k++) {
+            if (step0 + k < H) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    buf_load<NP>(cb[k][d], Cbuf, voff, (int)offl[d]);
+                    xl[d] += rx[d];
+                    offl[d] += stride[d];
+                }
+                wrap_load();
             }
         }
     };
@@ -404,54 +409,49 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
         }
         to_boundary--;
     };
-
-    auto compute_block = [&](Pack<NP>(*cb)[3], int step0) {
-        if (step0 >= H) return;
-        if (step0 + PB <= H && stays(xc[0], 0) && stays(xc[2], 2)) {
+    auto compute_fast = [&](Pack<NP>(*cb)[3], int step0) {
 #pragma unroll
-            for (int k = 0; k < PB; k++) {
+        for (int k = 0; k < PB; k++) {
+            one_step(cb[k], step0 + k + 1 < H);
+#pragma unroll
+            for (int d = 0; d < 3; d++) xc[d] += rx[d];
+        }
+    };
+    auto compute_slow = [&](Pack<NP>(*cb)[3], int step0) {
+#pragma unroll
+        for (int k = 0; k < PB; k++) {
+            if (step0 + k < H) {
                 one_step(cb[k], step0 + k + 1 < H);
 #pragma unroll
                 for (int d = 0; d < 3; d++) xc[d] += rx[d];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PB; k++) {
-                if (step0 + k < H) {
-                    one_step(cb[k], step0 + k + 1 < H);
-#pragma unroll
-                    for (int d = 0; d < 3; d++) {
-                        xc[d] += rx[d];
-                        if (xc[d] >= W1) {
-                            xc[d] = 0;
-                            L[d].fill(init);
-                        } else if (xc[d] < 0) {
-                            xc[d] = W1 - 1;
-                            L[d].fill(init);
-                        }
-                    }
-                }
-            }
-        }
-        // a line that reached the border exactly at the end of a straight block restarts here
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            if (xc[d] >= W1) {
-                xc[d] = 0;
-                L[d].fill(init);
-            } else if (xc[d] < 0) {
-                xc[d] = W1 - 1;
-                L[d].fill(init);
+                wrap_compute();
             }
         }
     };
 
-    load_block(cA, 0);
+    // block s0 is in cA (loaded here); each iteration loads s0+PB -> cB and s0+2PB -> cA
+    if (PB <= H && stays(xl[0], 0, PB) && stays(xl[2], 2, PB)) {
+        load_fast(cA);
+        wrap_load();
+    } else {
+        load_slow(cA, 0);
+    }
     for (int s0 = 0; s0 < H; s0 += 2 * PB) {
-        load_block(cB, s0 + PB);
-        compute_block(cA, s0);
-        load_block(cA, s0 + 2 * PB);
-        compute_block(cB, s0 + PB);
+        const bool fast = s0 + 3 * PB <= H && stays(xl[0], 0, 2 * PB) && stays(xl[2], 2, 2 * PB) &&
+                          stays(xc[0], 0, 2 * PB) && stays(xc[2], 2, 2 * PB);
+        if (fast) {
+            load_fast(cB);
+            compute_fast(cA, s0);
+            load_fast(cA);
+            compute_fast(cB, s0 + PB);
+            wrap_load();      // a cursor may stand exactly one past the border now
+            wrap_compute();
+        } else {
+            load_slow(cB, s0 + PB);
+            compute_slow(cA, s0);
+            load_slow(cA, s0 + 2 * PB);
+            compute_slow(cB, s0 + PB);
+        }
     }
 }
 
