@@ -82,7 +82,7 @@ __device__ __forceinline__ void path_normalise(const Pack<NP> &Ln, uint32_t m, b
 // weight, is below minS*100" -- one more packed wave reduction instead of per-element products
 // and boolean mask arithmetic.  Non-positive weights (uniquenessRatio >= 100) take the literal
 // per-element form.
-template <int NP, bool PARTIAL>
+template <int NP, bool PARTIAL, bool POSW>
 __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool active, int D, int uniq)
 {
     uint32_t kmin = 0xffffffffu;
@@ -99,7 +99,7 @@ __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool ac
     const int wgt = 100 - uniq;
     const int thr = minS * 100;
     bool reject;
-    if (wgt > 0) {
+    if (POSW) {  // wgt > 0 (the host picks the instantiation)
         uint32_t far = SGM_SENT;
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -129,7 +129,8 @@ __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool ac
     // all costs saturated: upstream keeps bestDisp = -1; the pixel ends invalid and never wins
     // a right-view slot (32767 > 32767 is false)
     reject = reject || (minS == SGM_MAX_COST);
-    // S[best-1], S[best+1]: lane (d / 2NP) holds d; read the lane's registers, pick the half
+    // S[best-1], S[best+1] (clamped to the range; k_select uses them only for 0 < best < D-1):
+    // lane (d / 2NP) holds d; read the lane's registers, pick the half
     auto fetch = [&](int d) -> uint32_t {
         const int ln = d / (2 * NP), e = d - ln * (2 * NP);  // element e of lane ln
         uint32_t v = __builtin_amdgcn_readlane(Sn.r[0], ln);
@@ -140,15 +141,12 @@ __device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool ac
         }
         return (e & 1) ? (v >> 16) : (v & 0xffffu);
     };
-    uint32_t nb = 0;
-    if (best > 0 && best < D - 1) nb = fetch(best - 1) | (fetch(best + 1) << 16);
+    const uint32_t nb = fetch(max(best - 1, 0)) | (fetch(min(best + 1, D - 1)) << 16);
     return make_uint2(reject ? 0xffffffffu : key, nb);
 }
 
 struct Cursor {
     int xi, y;
-    int64_t off;   // element offset of pixel (xi, y) in a [H][W1][D] volume, kept incrementally
-    int64_t woff;  // index of the pixel in the [H][W] WTA record image
 };
 
 // Band-boundary state written by the PATH_BOUNDARY pre-pass and read by k_sweep:
@@ -161,13 +159,26 @@ struct Boundary {
     int slot;    // which of the three slots this launch writes
 };
 
-template <int NP, bool PARTIAL, int MODE>
+// one image row of a [H][W1][D] int16 volume as a buffer resource (no 4 GiB limit on the volume)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const int16_t *vol, int y, int W1, int D)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(vol + (int64_t)y * W1 * D), 0, W1 * D * 2, 0x00020000);
+}
+
+// One direction, one wavefront per path line.  MODE: PATH_FIRST (S = L), PATH_ACCUM (S += L),
+// PATH_LAST (S += L, winner-take-all, S stored only if keepS), PATH_BOUNDARY (no S; the state at
+// band boundaries goes to bd.L; grid.y selects the role).  POSW: uniquenessRatio < 100 (the WTA
+// variant without per-element products).
+//
+// Prefetch discipline as in k_sweep: buffer loads/stores (constant per-lane offset register +
+// scalar offset inside the row), and iterations of two blocks in which the line neither ends
+// nor wraps around the image border are straight-line code.
+template <int NP, bool PARTIAL, int MODE, bool POSW>
 __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16_t *__restrict__ C,
                                              int16_t *__restrict__ S, int keepS,
                                              uint2 *__restrict__ wta, Boundary bd)
 {
-    // steps per prefetch block (two blocks in flight); deeper where registers allow
-    constexpr int PB = MODE == PATH_FIRST ? (NP == 4 ? 8 : 16) : 8;
+    constexpr int PB = 8;  // steps per prefetch block (two blocks in flight)
     const int lane = threadIdx.x;
     const int line = blockIdx.x;
     const int W1 = g.W1, D = g.D;
@@ -178,9 +189,12 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
     }
     const int nsteps = ry == 0 ? W1 : g.H;
     const bool active = !PARTIAL || (2 * NP * lane < D);
-    const int lane_off = active ? 2 * NP * lane : 0;  // idle lanes load lane 0's data (ignored)
+    const int lane_off = active ? 2 * NP * lane : 0;
+    const int voff = lane_off * 2;
+    const int pxb = D * 2;  // bytes per pixel
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     const uint32_t init = active ? 0u : SGM_SENT;  // idle lanes act as the d = D sentinel
+    constexpr bool READS_S = (MODE == PATH_ACCUM || MODE == PATH_LAST);
 
     Cursor ld, cp;  // load cursor runs ahead of the compute cursor
     if (ry == 0) {
@@ -190,100 +204,119 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
         ld.y = ry > 0 ? 0 : g.H - 1;
         ld.xi = line;
     }
-    ld.off = ((int64_t)ld.y * W1 + ld.xi) * D;
-    ld.woff = (int64_t)ld.y * g.W + g.minX1 + ld.xi;
     cp = ld;
-    const int64_t step_off = ((int64_t)ry * W1 + rx) * D, row_off = (int64_t)W1 * D;
-    const int64_t step_w = (int64_t)ry * g.W + rx;
 
-    auto advance = [&](Cursor &c) -> bool {  // returns true when the predecessor left the domain
-        c.xi += rx;
-        c.y += ry;
-        c.off += step_off;
-        c.woff += step_w;
+    auto wrap = [&](Cursor &c) -> bool {  // true when the line left the image and re-enters
         if (c.xi >= W1) {
             c.xi = 0;
-            c.off -= row_off;
-            c.woff -= W1;
             return true;
         }
         if (c.xi < 0) {
             c.xi = W1 - 1;
-            c.off += row_off;
-            c.woff += W1;
             return true;
         }
         return false;
     };
-
-    // PATH_BOUNDARY: rows until the next band boundary, and the band that boundary feeds
-    int to_boundary = bd.R - 1, next_band = 1;
+    auto stays = [&](const Cursor &c, int n) { const int xe = c.xi + (n - 1) * rx; return xe >= 0 && xe < W1; };
 
     Pack<NP> L;  // normalised state L_r(q,.) - min (all-zero when q is outside the domain)
     L.fill(init);
     ShiftRegs sr;
-
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
-    constexpr bool READS_S = (MODE == PATH_ACCUM || MODE == PATH_LAST);
+    int to_boundary = bd.R - 1, next_band = 1;  // PATH_BOUNDARY bookkeeping
 
-    auto load_block = [&](Pack<NP> *cb, Pack<NP> *sb, int step0) {
-        const bool full = step0 + PB <= nsteps;  // all but the last block: no per-step guard
+    auto load_fast = [&](Pack<NP> *cb, Pack<NP> *sb) {
 #pragma unroll
         for (int k = 0; k < PB; k++) {
-            if (full || step0 + k < nsteps) {
-                cb[k].load(C + ld.off + lane_off);
-                if (READS_S) sb[k].load(S + ld.off + lane_off);
-                advance(ld);
+            const int y = ld.y + k * ry, so = (ld.xi + k * rx) * pxb;
+            buf_load<NP>(cb[k], row_rsrc(C, y, W1, D), voff, so);
+            if (READS_S) buf_load<NP>(sb[k], row_rsrc(S, y, W1, D), voff, so);
+        }
+        ld.xi += PB * rx;
+        ld.y += PB * ry;
+    };
+    auto load_slow = [&](Pack<NP> *cb, Pack<NP> *sb, int step0) {
+#pragma unroll
+        for (int k = 0; k < PB; k++) {
+            if (step0 + k < nsteps) {
+                buf_load<NP>(cb[k], row_rsrc(C, ld.y, W1, D), voff, ld.xi * pxb);
+                if (READS_S) buf_load<NP>(sb[k], row_rsrc(S, ld.y, W1, D), voff, ld.xi * pxb);
+                ld.xi += rx;
+                ld.y += ry;
+                wrap(ld);
             }
         }
     };
 
-    auto compute_block = [&](Pack<NP> *cb, Pack<NP> *sb, int step0) {
-        const bool full = step0 + PB <= nsteps;
+    auto one_step = [&](const Pack<NP> &cv, const Pack<NP> &sv, bool more) {
+        Pack<NP> Ln, Lnorm;
+        uint32_t rmin;
+        path_elem<NP, PARTIAL>(cv, L, P1s, P2s, active, Ln, rmin, sr);
+        path_normalise<NP, PARTIAL>(Ln, halves_min(wave_min_pk(rmin)), active, Lnorm);
+        if (MODE == PATH_BOUNDARY) {
+            // state of the last row of a band, consumed by the first row of the next band
+            if (to_boundary == 0) {
+                const int64_t px = (int64_t)next_band * W1 + cp.xi;
+                if (active && more) Lnorm.store(bd.L + (px * 3 + bd.slot) * D + lane_off);
+                to_boundary = bd.R;
+                next_band++;
+            }
+            to_boundary--;
+        } else {
+            Pack<NP> Sn;
+#pragma unroll
+            for (int i = 0; i < NP; i++) Sn.r[i] = MODE == PATH_FIRST ? Ln.r[i] : pk_adds_s(sv.r[i], Ln.r[i]);
+            if (MODE != PATH_LAST || keepS) {
+                if (active) buf_store<NP>(Sn, row_rsrc(S, cp.y, W1, D), voff, cp.xi * pxb);
+            }
+            if (MODE == PATH_LAST) {
+                const uint2 rec = wta_pixel<NP, PARTIAL, POSW>(Sn, lane, active, D, g.uniq);
+                if (lane == 0) wta[(int64_t)cp.y * g.W + g.minX1 + cp.xi] = rec;
+            }
+        }
+        L = Lnorm;
+    };
+    auto compute_fast = [&](Pack<NP> *cb, Pack<NP> *sb, int step0) {
 #pragma unroll
         for (int k = 0; k < PB; k++) {
-            if (full || step0 + k < nsteps) {
-                Pack<NP> Ln, Lnorm;
-                uint32_t rmin;
-                path_elem<NP, PARTIAL>(cb[k], L, P1s, P2s, active, Ln, rmin, sr);
-                path_normalise<NP, PARTIAL>(Ln, halves_min(wave_min_pk(rmin)), active, Lnorm);
-
-                if (MODE == PATH_BOUNDARY) {
-                    // state of the last row of a band, consumed by the first row of the next band
-                    if (to_boundary == 0) {
-                        const int64_t px = (int64_t)next_band * W1 + cp.xi;
-                        if (active && step0 + k + 1 < nsteps) Lnorm.store(bd.L + (px * 3 + bd.slot) * D + lane_off);
-                        to_boundary = bd.R;
-                        next_band++;
-                    }
-                    to_boundary--;
-                } else {
-                    const int64_t off = cp.off + lane_off;
-                    Pack<NP> Sn;
+            one_step(cb[k], sb[k], step0 + k + 1 < nsteps);
+            cp.xi += rx;
+            cp.y += ry;
+        }
+    };
+    auto compute_slow = [&](Pack<NP> *cb, Pack<NP> *sb, int step0) {
 #pragma unroll
-                    for (int i = 0; i < NP; i++)
-                        Sn.r[i] = MODE == PATH_FIRST ? Ln.r[i] : pk_adds_s(sb[k].r[i], Ln.r[i]);
-                    if (MODE != PATH_LAST || keepS) {
-                        if (active) Sn.store(S + off);
-                    }
-                    if (MODE == PATH_LAST) {
-                        const uint2 rec = wta_pixel<NP, PARTIAL>(Sn, lane, active, D, g.uniq);
-                        if (lane == 0) wta[cp.woff] = rec;
-                    }
-                }
-
-                L = Lnorm;
-                if (advance(cp)) L.fill(init);
+        for (int k = 0; k < PB; k++) {
+            if (step0 + k < nsteps) {
+                one_step(cb[k], sb[k], step0 + k + 1 < nsteps);
+                cp.xi += rx;
+                cp.y += ry;
+                if (wrap(cp)) L.fill(init);
             }
         }
     };
 
-    load_block(cA, sA, 0);
+    if (PB <= nsteps && stays(ld, PB)) {
+        load_fast(cA, sA);
+        wrap(ld);
+    } else {
+        load_slow(cA, sA, 0);
+    }
     for (int s0 = 0; s0 < nsteps; s0 += 2 * PB) {
-        load_block(cB, sB, s0 + PB);
-        compute_block(cA, sA, s0);
-        load_block(cA, sA, s0 + 2 * PB);
-        compute_block(cB, sB, s0 + PB);
+        const bool fast = s0 + 3 * PB <= nsteps && stays(ld, 2 * PB) && stays(cp, 2 * PB);
+        if (fast) {
+            load_fast(cB, sB);
+            compute_fast(cA, sA, s0);
+            load_fast(cA, sA);
+            compute_fast(cB, sB, s0 + PB);
+            wrap(ld);  // a cursor may stand exactly one past the border now
+            if (wrap(cp)) L.fill(init);
+        } else {
+            load_slow(cB, sB, s0 + PB);
+            compute_slow(cA, sA, s0);
+            load_slow(cA, sA, s0 + 2 * PB);
+            compute_slow(cB, sB, s0 + PB);
+        }
     }
 }
 

@@ -71,7 +71,7 @@ __device__ __forceinline__ void lds_store(const Pack<NP> &p, uint32_t *dst)
     *reinterpret_cast<typename PackVec<NP>::type *>(dst) = v;
 }
 
-template <int NP, bool PARTIAL, int MODE>
+template <int NP, bool PARTIAL, int MODE, bool POSW>
 __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, SweepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
             if (active) buf_store<NP>(Sn, Srow, voff, b0 + k * bk);
         }
         if (MODE == SWEEP_LAST) {
-            const uint2 rec = wta_pixel<NP, PARTIAL>(Sn, lane, active, D, g.uniq);
+            const uint2 rec = wta_pixel<NP, PARTIAL, POSW>(Sn, lane, active, D, g.uniq);
             if (lane == 0) wrow[k * wk] = rec;
         }
     };

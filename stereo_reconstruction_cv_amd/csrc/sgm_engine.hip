@@ -171,14 +171,17 @@ static void launch_path_np(const Geom &g, int rx, int ry, int mode, const int16_
 {
     const int nlines = ry == 0 ? g.H : g.W1;
     dim3 grid(nlines, mode == PATH_BOUNDARY ? 3 : 1), block(64);
+    const bool posw = g.uniq < 100;  // positive uniqueness weight: the WTA variant without products
     if (mode == PATH_FIRST)
-        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_FIRST>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_FIRST, true>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
     else if (mode == PATH_ACCUM)
-        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_ACCUM>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_ACCUM, true>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
+    else if (mode == PATH_LAST && posw)
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_LAST, true>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
     else if (mode == PATH_LAST)
-        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_LAST>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_LAST, false>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
     else
-        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_BOUNDARY>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
+        hipLaunchKernelGGL((k_path<NP, PARTIAL, PATH_BOUNDARY, true>), grid, block, 0, st, g, rx, ry, C, S, keepS, wta, bd);
 }
 
 static void launch_path(const Geom &g, int rx, int ry, int mode, const int16_t *C, int16_t *S, int keepS,
@@ -198,20 +201,21 @@ static void launch_path(const Geom &g, int rx, int ry, int mode, const int16_t *
 }
 
 // ---- sweep launch dispatch --------------------------------------------------------------------
-template <int NP, bool PARTIAL, int MODE>
+template <int NP, bool PARTIAL, int MODE, bool POSW>
 static int launch_sweep_one(const Geom &g, const SweepArgs &a, int nbands, hipStream_t st)
 {
     const size_t lds = sweep_lds_bytes(NP, a.R);
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<NP, PARTIAL, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_sweep<NP, PARTIAL, MODE>), dim3(nbands), dim3((a.R + 1) * 64), lds, st, g, a);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<NP, PARTIAL, MODE, POSW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_sweep<NP, PARTIAL, MODE, POSW>), dim3(nbands), dim3((a.R + 1) * 64), lds, st, g, a);
     return SGM_OK;
 }
 template <int NP, bool PARTIAL>
 static int launch_sweep_np(const Geom &g, const SweepArgs &a, int mode, int nbands, hipStream_t st)
 {
-    if (mode == SWEEP_FIRST) return launch_sweep_one<NP, PARTIAL, SWEEP_FIRST>(g, a, nbands, st);
-    if (mode == SWEEP_ACCUM) return launch_sweep_one<NP, PARTIAL, SWEEP_ACCUM>(g, a, nbands, st);
-    return launch_sweep_one<NP, PARTIAL, SWEEP_LAST>(g, a, nbands, st);
+    if (mode == SWEEP_FIRST) return launch_sweep_one<NP, PARTIAL, SWEEP_FIRST, true>(g, a, nbands, st);
+    if (mode == SWEEP_ACCUM) return launch_sweep_one<NP, PARTIAL, SWEEP_ACCUM, true>(g, a, nbands, st);
+    if (g.uniq < 100) return launch_sweep_one<NP, PARTIAL, SWEEP_LAST, true>(g, a, nbands, st);
+    return launch_sweep_one<NP, PARTIAL, SWEEP_LAST, false>(g, a, nbands, st);
 }
 static int launch_sweep(const Geom &g, const SweepArgs &a, int mode, int nbands, hipStream_t st)
 {
