@@ -434,7 +434,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // MODE_HH: the upward pre-pass only reads C, so it runs on the auxiliary stream while the
             // main stream does the downward pre-pass and sweep (memory-bound beside issue-bound work)
             const bool overlap = npass == 2 && nbands > 1 && !(e->debug & 32);
-            if (overlap) {
+            auto fork_prepass_up = [&]() -> int {  // aux stream: upward pre-pass, from "now" on the main stream
+                int rc2;
                 if (!e->aux) {
                     HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
                     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -442,12 +443,17 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 }
                 HIP_TRY(hipEventRecord(e->ev_fork, st));
                 HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-                if ((rc = stage_begin(e, "prepass_up", e->aux))) return rc;
+                if ((rc2 = stage_begin(e, "prepass_up", e->aux))) return rc2;
                 launch_prepass(-1, -1, (int16_t *)e->bndL2.p, e->aux);
                 KCHECK();
-                if ((rc = stage_end(e, 1, e->aux))) return rc;
+                if ((rc2 = stage_end(e, 1, e->aux))) return rc2;
                 HIP_TRY(hipEventRecord(e->ev_join, e->aux));
-            }
+                return SGM_OK;
+            };
+            // debug bit 64+128: fork right after the cost stage (both pre-passes side by side) instead
+            // of after the downward pre-pass (upward pre-pass beside the downward sweep)
+            const bool fork_early = (e->debug & 128) != 0;
+            if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
                 int16_t *bl = (int16_t *)(pass == 0 ? e->bndL.p : e->bndL2.p);
@@ -457,6 +463,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     KCHECK();
                     if ((rc = stage_end(e, 1))) return rc;
                 }
+                if (overlap && pass == 0 && !fork_early && (rc = fork_prepass_up())) return rc;
                 if (overlap && pass == 1) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
                 SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug};
                 const bool last = pass == npass - 1 && g.mode == 1;
