@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsgm_hip.so")
+# SGM_HIP_LIB: developer override (A/B runs of experimental builds); the product path is the in-tree library
+LIB_PATH = os.environ.get("SGM_HIP_LIB") or os.path.join(_HERE, "csrc", "libsgm_hip.so")
 
 SGM_OK = 0
 SGM_TAP_COST, SGM_TAP_AGGR, SGM_TAP_DISP_RAW, SGM_TAP_DISP_MEDIAN = 0, 1, 2, 3

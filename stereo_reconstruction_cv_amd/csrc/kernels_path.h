@@ -74,75 +74,123 @@ __device__ __forceinline__ void path_normalise(const Pack<NP> &Ln, uint32_t m, b
     }
 }
 
-// Winner-take-all on the finished S of one pixel (A.6 steps 1-2; steps 3-4 run in k_select):
-// returns the record {reject ? ~0 : (minS << 16 | first best d), S[best-1] | S[best+1] << 16}.
+// Winner-take-all on the finished S of one pixel (A.6 steps 1-2; steps 3-4 run in k_select).
+// Writes the record {reject ? ~0 : (minS << 16 | first best d), S[best-1] | S[best+1] << 16} to
+// *rec: lane 0 stores the first word; the two halves of the second word are stored by whichever
+// lanes hold disparities best-1 and best+1 (nobody, if they are outside [0, D) -- k_select reads
+// them only for 0 < best < D-1).
 //
 // Uniqueness (upstream: reject if some d with |d - best| > 1 has S[d]*(100-uniq) < minS*100):
 // for a positive weight that is "the smallest S outside {best-1, best, best+1}, times the
 // weight, is below minS*100" -- one more packed wave reduction instead of per-element products
-// and boolean mask arithmetic.  Non-positive weights (uniquenessRatio >= 100) take the literal
-// per-element form.
-template <int NP, bool PARTIAL, bool POSW>
-__device__ __forceinline__ uint2 wta_pixel(const Pack<NP> &Sn, int lane, bool active, int D, int uniq)
+// and boolean mask arithmetic.  Non-positive weights (uniquenessRatio >= 100, POSW = false) take
+// the literal per-element form.
+// N pixels at a time (their reduction chains interleave; see wave_min_pk_n).  All stores come
+// last so that both chains and the per-lane selects around them sit in one basic block.
+template <int NP, bool PARTIAL, bool POSW, int N>
+__device__ __forceinline__ void wta_pixels(const Pack<NP> (&Sn)[N], int lane, bool active, int D, int uniq,
+                                           uint2 *const (&rec)[N])
 {
-    uint32_t kmin = 0xffffffffu;
+    // packed constants in SGPRs: as inline operands they need op_sel_hi, and a VALU result
+    // produced with op_sel costs its consumer a wait state on gfx950
+    uint32_t c3, c15;
+    asm("s_mov_b32 %0, 0x30003" : "=s"(c3));
+    asm("s_mov_b32 %0, 0xf000f" : "=s"(c15));
+    uint32_t key[N];
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-        const uint32_t d0 = 2u * (NP * lane + i);
-        const uint32_t klo = (Sn.r[i] << 16) | d0;
-        const uint32_t khi = (Sn.r[i] & 0xffff0000u) | (d0 + 1u);
-        kmin = min(kmin, min(klo, khi));
+    for (int n = 0; n < N; n++) {
+        uint32_t kmin = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const uint32_t d0 = 2u * (NP * lane + i);
+            const uint32_t klo = (Sn[n].r[i] << 16) | d0;
+            const uint32_t khi = (Sn[n].r[i] & 0xffff0000u) | (d0 + 1u);
+            kmin = min(kmin, min(klo, khi));
+        }
+        if (PARTIAL && !active) kmin = 0xffffffffu;
+        key[n] = kmin;
     }
-    if (PARTIAL && !active) kmin = 0xffffffffu;
-    const uint32_t key = wave_min_u32(kmin);  // (minS << 16) | first best d
-    const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
+    wave_min_u32_n<N>(key);  // (minS << 16) | first best d
     const int wgt = 100 - uniq;
-    const int thr = minS * 100;
-    bool reject;
-    if (POSW) {  // wgt > 0 (the host picks the instantiation)
-        uint32_t far = SGM_SENT;
+    uint32_t far[N], vm[N], vp[N];
+    bool has_m[N], has_p[N];
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        const int best = (int)(key[n] & 0xffffu);
+        // e_i = d_lo(i) - (best - 1): the low half is best-1 / best / best+1 for e = 0 / 1 / 2,
+        // the high half (d_lo + 1) for e = -1 / 0 / 1
+        uint32_t f = SGM_SENT;
+        vm[n] = vp[n] = 0;
+        has_m[n] = has_p[n] = false;
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            // e = d_lo - (best - 1): the low half is near best for e in {0,1,2}, the high half
-            // (d_lo + 1) for e in {-1,0,1}; S <= 0x7fff, so OR-ing 0x7fff makes a half "infinite"
             const int e = 2 * (NP * lane + i) - best + 1;
-            uint32_t v = Sn.r[i];
-            v |= ((uint32_t)e <= 2u) ? 0x00007fffu : 0u;
-            v |= ((uint32_t)(e + 1) <= 2u) ? 0x7fff0000u : 0u;
-            far = pk_min_s(far, v);
+            const uint32_t v = Sn[n].r[i];
+            if (e == 0 || e == -1) {
+                vm[n] = e == 0 ? (v & 0xffffu) : (v >> 16);
+                has_m[n] = true;
+            }
+            if (e == 2 || e == 1) {
+                vp[n] = e == 2 ? (v & 0xffffu) : (v >> 16);
+                has_p[n] = true;
+            }
+            if (POSW) {
+                // per half: d - best + 1 in 0..2 <=> the disparity is one of best-1..best+1; those
+                // halves are forced to 0x7fff (S <= 0x7fff, so OR does it) -- packed, no VCC
+                const uint32_t u = pk_sub(splat16(2u * (NP * lane + i) + 1u) + 0x10000u, splat16(best));
+                const uint32_t t = bits(as_s(pk_sub(pk_min_u(u, c3), c3)) >> as_s(c15));
+                f = pk_min_s(f, (t & SGM_SENT) | v);
+            }
         }
-        if (PARTIAL && !active) far = SGM_SENT;
-        const int m2 = (int)halves_min(wave_min_pk(far));  // D >= 16: far disparities always exist
-        reject = m2 * wgt < thr;
-    } else {
-        bool bad = false;
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const int d0 = 2 * (NP * lane + i);
-            const int slo = (int)(Sn.r[i] & 0xffffu), shi = (int)(Sn.r[i] >> 16);
-            bad |= (__mul24(slo, wgt) < thr) && (abs(best - d0) > 1);
-            bad |= (__mul24(shi, wgt) < thr) && (abs(best - d0 - 1) > 1);
+        if (PARTIAL) {
+            has_m[n] = has_m[n] && active;
+            has_p[n] = has_p[n] && active;
+            if (!active) f = SGM_SENT;
         }
-        if (PARTIAL) bad = bad && active;
-        reject = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+        far[n] = min(f & 0xffffu, f >> 16);  // one value per lane: the chain can use v_min_u32_dpp
     }
-    // all costs saturated: upstream keeps bestDisp = -1; the pixel ends invalid and never wins
-    // a right-view slot (32767 > 32767 is false)
-    reject = reject || (minS == SGM_MAX_COST);
-    // S[best-1], S[best+1] (clamped to the range; k_select uses them only for 0 < best < D-1):
-    // lane (d / 2NP) holds d; read the lane's registers, pick the half
-    auto fetch = [&](int d) -> uint32_t {
-        const int ln = d / (2 * NP), e = d - ln * (2 * NP);  // element e of lane ln
-        uint32_t v = __builtin_amdgcn_readlane(Sn.r[0], ln);
+    if (POSW) wave_min_u32_n<N>(far);  // D >= 16: disparities outside best-1..best+1 always exist
 #pragma unroll
-        for (int q = 1; q < NP; q++) {
-            const uint32_t w = __builtin_amdgcn_readlane(Sn.r[q], ln);
-            v = (e >> 1) == q ? w : v;
+    for (int n = 0; n < N; n++) {
+        const int minS = (int)(key[n] >> 16), best = (int)(key[n] & 0xffffu);
+        const int thr = minS * 100;
+        bool reject;
+        if (POSW) {  // wgt > 0 (the host picks the instantiation)
+            reject = (int)far[n] * wgt < thr;
+        } else {
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int d0 = 2 * (NP * lane + i);
+                const int slo = (int)(Sn[n].r[i] & 0xffffu), shi = (int)(Sn[n].r[i] >> 16);
+                bad |= (__mul24(slo, wgt) < thr) && (abs(best - d0) > 1);
+                bad |= (__mul24(shi, wgt) < thr) && (abs(best - d0 - 1) > 1);
+            }
+            if (PARTIAL) bad = bad && active;
+            reject = __builtin_amdgcn_ballot_w64(bad) != 0ull;
         }
-        return (e & 1) ? (v >> 16) : (v & 0xffffu);
-    };
-    const uint32_t nb = fetch(max(best - 1, 0)) | (fetch(min(best + 1, D - 1)) << 16);
-    return make_uint2(reject ? 0xffffffffu : key, nb);
+        // all costs saturated: upstream keeps bestDisp = -1; the pixel ends invalid and never
+        // wins a right-view slot (32767 > 32767 is false)
+        reject = reject || (minS == SGM_MAX_COST);
+        // The three values are materialised in VGPRs of their own under the full EXEC mask; only
+        // the stores themselves run under a partial mask.  (gfx950, seen with NP = 4: when hipcc
+        // sank these selects into the masked blocks it reused the registers of the S vector whose
+        // buffer_store_dwordx4 had just been issued, and the stored S came out wrong in a few
+        // lanes now and then -- tools/dbg_case.py, DESIGN.md 4.3 "masked writes after wide stores".)
+        uint32_t kv = reject ? 0xffffffffu : key[n], m16 = vm[n], p16 = vp[n];
+        asm volatile("" : "+v"(kv), "+v"(m16), "+v"(p16));
+        uint16_t *nb = reinterpret_cast<uint16_t *>(&rec[n]->y);
+        if (has_m[n]) nb[0] = (uint16_t)m16;
+        if (has_p[n]) nb[1] = (uint16_t)p16;
+        if (lane == 0) rec[n]->x = kv;
+    }
+}
+template <int NP, bool PARTIAL, bool POSW>
+__device__ __forceinline__ void wta_pixel(const Pack<NP> &Sn, int lane, bool active, int D, int uniq, uint2 *rec)
+{
+    const Pack<NP> S1[1] = {Sn};
+    uint2 *const r1[1] = {rec};
+    wta_pixels<NP, PARTIAL, POSW, 1>(S1, lane, active, D, uniq, r1);
 }
 
 struct Cursor {
@@ -270,8 +318,7 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
                 if (active) buf_store<NP>(Sn, row_rsrc(S, cp.y, W1, D), voff, cp.xi * pxb);
             }
             if (MODE == PATH_LAST) {
-                const uint2 rec = wta_pixel<NP, PARTIAL, POSW>(Sn, lane, active, D, g.uniq);
-                if (lane == 0) wta[(int64_t)cp.y * g.W + g.minX1 + cp.xi] = rec;
+                wta_pixel<NP, PARTIAL, POSW>(Sn, lane, active, D, g.uniq, wta + ((int64_t)cp.y * g.W + g.minX1 + cp.xi));
             }
         }
         L = Lnorm;

@@ -259,6 +259,10 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         (void *)(a.C + (int64_t)y * W1 * D), 0, row_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t Srow = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.S + (int64_t)y * W1 * D), 0, row_bytes, 0x00020000);
+    // stores of S go through a descriptor of their own: zero records (every store dropped by the
+    // bounds check) when the last sweep need not keep S -- no branch inside the step
+    const __amdgpu_buffer_rsrc_t Sst = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.S + (int64_t)y * W1 * D), 0, (MODE != SWEEP_LAST || a.keepS) ? row_bytes : 0, 0x00020000);
     const int voff = lane_off * 2;
     const int bk = a.xdir > 0 ? D * 2 : -D * 2;
     const int b0 = a.xdir > 0 ? 0 : (W1 - 1) * D * 2;
@@ -305,13 +309,8 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
             if (READS_S) v = pk_adds_s(v, Sp.r[i]);
             Sn.r[i] = v;
         }
-        if (MODE != SWEEP_LAST || a.keepS) {
-            if (active) buf_store<NP>(Sn, Srow, voff, b0 + k * bk);
-        }
-        if (MODE == SWEEP_LAST) {
-            const uint2 rec = wta_pixel<NP, PARTIAL, POSW>(Sn, lane, active, D, g.uniq);
-            if (lane == 0) wrow[k * wk] = rec;
-        }
+        if (!PARTIAL || active) buf_store<NP>(Sn, Sst, voff, b0 + k * bk);
+        return Sn;
     };
 
     auto compute_block_t = [&](auto full_c, Pack<NP> *cb, Pack<NP> *sb, int k0) {  // k0 % PB == 0
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         for (int u0 = 0; u0 < PB; u0 += PPS) {
             if (FULL || k0 + u0 < W1) {
                 // normalised state of the row above for the PPS pixels of this step (LDS)
-                Pack<NP> QA[PPS], QB[PPS], QC[PPS];
+                Pack<NP> QA[PPS], QB[PPS], QC[PPS], Sn[PPS];
 #pragma unroll
                 for (int p = 0; p < PPS; p++) {
                     const int u = u0 + p;
@@ -331,7 +330,20 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
 #pragma unroll
                 for (int p = 0; p < PPS; p++) {
                     const int u = u0 + p;
-                    if (FULL || k0 + u < W1) pixel(cb[u], sb[u], QA[p], QB[p], QC[p], u, k0 + u);
+                    if (FULL || k0 + u < W1) Sn[p] = pixel(cb[u], sb[u], QA[p], QB[p], QC[p], u, k0 + u);
+                }
+                if (MODE == SWEEP_LAST) {  // winner-take-all of the step's pixels, chains interleaved
+                    if (FULL || k0 + u0 + PPS <= W1) {
+                        uint2 *recs[PPS];
+#pragma unroll
+                        for (int p = 0; p < PPS; p++) recs[p] = wrow + (k0 + u0 + p) * wk;
+                        wta_pixels<NP, PARTIAL, POSW, PPS>(Sn, lane, active, D, g.uniq, recs);
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < PPS; p++)
+                            if (k0 + u0 + p < W1)
+                                wta_pixel<NP, PARTIAL, POSW>(Sn[p], lane, active, D, g.uniq, wrow + (k0 + u0 + p) * wk);
+                    }
                 }
                 wg_barrier();
             }

@@ -92,6 +92,37 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
+// N independent reductions with their DPP steps interleaved: a DPP read needs two wait states
+// after the VALU write of its source, which a second chain fills (a lone chain gets s_nop's).
+template <int N> __device__ __forceinline__ void wave_min_pk_n(uint32_t (&x)[N])
+{
+#define SGM_STEP(CTRL, MASK)                                                        \
+    _Pragma("unroll") for (int n = 0; n < N; n++) x[n] = pk_min_s(x[n], dpp_view<CTRL, MASK>(x[n]));
+    SGM_STEP(DPP_QUAD_1032, 0xf)
+    SGM_STEP(DPP_QUAD_2301, 0xf)
+    SGM_STEP(DPP_ROW_HALF_MIRROR, 0xf)
+    SGM_STEP(DPP_ROW_MIRROR, 0xf)
+    SGM_STEP(DPP_ROW_BCAST15, 0xa)
+    SGM_STEP(DPP_ROW_BCAST31, 0xc)
+#undef SGM_STEP
+#pragma unroll
+    for (int n = 0; n < N; n++) x[n] = __builtin_amdgcn_readlane(x[n], 63);
+}
+template <int N> __device__ __forceinline__ void wave_min_u32_n(uint32_t (&x)[N])
+{
+#define SGM_STEP(CTRL, MASK)                                                        \
+    _Pragma("unroll") for (int n = 0; n < N; n++) x[n] = min(x[n], dpp_view<CTRL, MASK>(x[n]));
+    SGM_STEP(DPP_QUAD_1032, 0xf)
+    SGM_STEP(DPP_QUAD_2301, 0xf)
+    SGM_STEP(DPP_ROW_HALF_MIRROR, 0xf)
+    SGM_STEP(DPP_ROW_MIRROR, 0xf)
+    SGM_STEP(DPP_ROW_BCAST15, 0xa)
+    SGM_STEP(DPP_ROW_BCAST31, 0xc)
+#undef SGM_STEP
+#pragma unroll
+    for (int n = 0; n < N; n++) x[n] = __builtin_amdgcn_readlane(x[n], 63);
+}
+
 // NP packed registers per lane, moved as one vector access
 template <int NP> struct PackVec;
 template <> struct PackVec<1> { typedef uint32_t type; };
@@ -153,12 +184,20 @@ __device__ __forceinline__ void buf_store(const Pack<NP> &p, __amdgpu_buffer_rsr
         v.y = p.r[1];
         __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff_bytes, soff_bytes, 0);
     } else {
-        v4u32 v;
-        v.x = p.r[0];
-        v.y = p.r[1];
-        v.z = p.r[2];
-        v.w = p.r[3];
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff_bytes, soff_bytes, 0);
+        // Two 64-bit stores, never buffer_store_dwordx4.  Round 1 found (MI355X, ROCm 7.2) that a
+        // buffer_store_dwordx4 with an SGPR soffset can pick up a later value of its data VGPRs
+        // when those are rewritten before the wave's next long wait: now and then dword 0 of
+        // lanes 12-15 of every 16 came out wrong in the stored S (NP = 4 sweeps; the compiler
+        // sees no hazard for this form and inserts nothing).  The 64-bit form has never shown
+        // it.  The empty asm keeps the two halves from being merged again.
+        v2u32 lo, hi;
+        lo.x = p.r[0];
+        lo.y = p.r[1];
+        hi.x = p.r[2];
+        hi.y = p.r[3];
+        __builtin_amdgcn_raw_buffer_store_b64(lo, rsrc, voff_bytes, soff_bytes, 0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_raw_buffer_store_b64(hi, rsrc, voff_bytes + 8, soff_bytes, 0);
     }
 }
 

@@ -465,8 +465,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 }
                 if (overlap && pass == 0 && !fork_early && (rc = fork_prepass_up())) return rc;
                 if (overlap && pass == 1) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
-                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug};
                 const bool last = pass == npass - 1 && g.mode == 1;
+                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug};
                 if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : "sweep_up_wta"))) return rc;
                 if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) return rc;
                 KCHECK();

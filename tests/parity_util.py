@@ -17,8 +17,10 @@ def params(D, bs, minD=0, mode=0, **kw):
     return p
 
 
-def run_hip_with_taps(left, right, p, schedule=1, sweep_rows=0):
+def run_hip_with_taps(left, right, p, schedule=1, sweep_rows=0, debug=0):
     eng = Engine(p)
+    if debug:
+        eng.set_option(_lib.SGM_OPT_DEBUG, debug)
     eng.set_option(_lib.SGM_OPT_KEEP_AGGR, 1)
     eng.set_option(_lib.SGM_OPT_SCHEDULE, schedule)
     eng.set_option(_lib.SGM_OPT_SWEEP_ROWS, sweep_rows)
