@@ -105,7 +105,22 @@ static inline HsumLds hsum_lds_layout(int NP, int RS, int XL, int SW2)
     return l;
 }
 
-template <int NP>
+// byte B of x in both halves of a packed pair (one v_perm_b32)
+template <int B> __device__ __forceinline__ uint32_t splat_byte(uint32_t x)
+{
+    return __builtin_amdgcn_perm(x, x, 0x0c000c00u | (uint32_t)B | ((uint32_t)B << 16));
+}
+
+// One wave per (row, chunk of XL output columns).  Column j of the pixel cost is computed once (BT
+// of the left record against the sliding windows of the six right-image planes), kept in an LDS
+// ring of RS columns, and the running horizontal sum hs(x) = hs(x-1) + pix(x+r) - pix(x-r-1)
+// (A.4, clamped at the domain edges) is stored as soon as its right-most tap exists.
+//
+// RS_T > 0 (= RS, a power of two) adds the interior fast path: RS_T columns per iteration,
+// unrolled, so ring slots, window taps and record reads are immediate offsets and the only
+// scalar work per column is the store offset; it covers every column whose window is not
+// clamped.  The generic per-column step handles the first and last columns of a chunk / row.
+template <int NP, int RS_T>
 __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ lrec,
                                              const uint8_t *__restrict__ rplanes,
                                              int16_t *__restrict__ hsum, int XL, int nchunks, int RS,
@@ -157,9 +172,16 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
 #pragma unroll
     for (int i = 0; i < NP; i++) hs[i] = 0;
     int next_x = xs;
-    int16_t *out_row = hsum + (int64_t)y * g.rowsz + 2 * NP * lane;
+    // this row of the output as a buffer resource; lanes past D get an out-of-range offset, so
+    // their stores are dropped by the bounds check instead of by a branch
+    const int row_bytes = W1 * g.D * 2;
+    const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(hsum + (int64_t)y * g.rowsz), 0, row_bytes, 0x00020000);
+    const int voff = active ? 4 * NP * lane : row_bytes;
+    const int pxb = g.D * 2;
 
-    for (int j = j0; j <= j1; j++) {
+    // the generic step: column j with every clamp and the first-output special case
+    auto column = [&](int j) {
         if (j > j0) {
             const int off = (j1 - j) + 2 * NP * lane;
 #pragma unroll
@@ -171,8 +193,8 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
             }
         }
         const uint2 rec = lds_lrec[j - j0];
-        const uint32_t U = splat16(rec.x & 0xff), U0 = splat16((rec.x >> 8) & 0xff), U1 = splat16((rec.x >> 16) & 0xff);
-        const uint32_t R = splat16(rec.y & 0xff), R0 = splat16((rec.y >> 8) & 0xff), R1 = splat16((rec.y >> 16) & 0xff);
+        const uint32_t U = splat_byte<0>(rec.x), U0 = splat_byte<1>(rec.x), U1 = splat_byte<2>(rec.x);
+        const uint32_t R = splat_byte<0>(rec.y), R0 = splat_byte<1>(rec.y), R1 = splat_byte<2>(rec.y);
         uint32_t *slot = ring + ((j & (RS - 1)) * 64 + lane) * NP;
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -198,15 +220,71 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
 #pragma unroll
                 for (int i = 0; i < NP; i++) hs[i] = pk_sub(pk_add(hs[i], pa[i]), pb[i]);
             }
-            if (active) {
-                Pack<NP> o;
+            Pack<NP> o;
 #pragma unroll
-                for (int i = 0; i < NP; i++) o.r[i] = hs[i];
-                o.store(out_row + (int64_t)x * g.D);
-            }
+            for (int i = 0; i < NP; i++) o.r[i] = hs[i];
+            buf_store<NP>(o, orow, voff, x * pxb);
             next_x++;
         }
+    };
+
+    int j = j0;
+    if (RS_T > 0) {
+        const int bs = 2 * SW2 + 1;
+        // fast columns: exactly one output x = j - SW2, not the chunk's first, no clamped tap:
+        //   x > xs, x - SW2 - 1 >= max(0, j0) (the outgoing tap is in the ring), j <= W1 - 2
+        int ja = max(xs + 1 + SW2, j0 + bs);
+        ja = (ja + RS_T - 1) & ~(RS_T - 1);
+        const int jb = min(xe - 1 + SW2, W1 - 2);  // last fast column
+        if (ja + RS_T - 1 <= jb) {
+            for (; j < ja; j++) column(j);
+            const uint32_t *ring_lane = ring + lane * NP;
+            uint32_t *ring_lane_w = ring + lane * NP;
+            // per-lane tap addresses of the six planes for the block's LAST column (offsets then
+            // count up towards the block's first column), and the record address of its first
+            int tap[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) tap[c] = c * seg_len + 2 * NP * lane + (j1 - j) - (RS_T - 1);
+            // the record address is the same in every lane; hidden from the compiler so that the
+            // record stays in VGPRs (v_perm splats) instead of a readfirstlane + scalar unpack
+            int recp = j - j0;
+            asm volatile("" : "+v"(recp));
+            int so = (j - SW2) * pxb;
+            for (; j + RS_T - 1 <= jb; j += RS_T) {
+#pragma unroll
+                for (int u = 0; u < RS_T; u++) {  // column j + u, ring slot u
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        const uint32_t nw = seg[tap[c] + (RS_T - 1 - u)];
+#pragma unroll
+                        for (int i = NP - 1; i >= 1; i--) w[c][i] = __builtin_amdgcn_alignbit(w[c][i], w[c][i - 1], 16);
+                        w[c][0] = (w[c][0] << 16) | nw;
+                    }
+                    const uint2 rec = lds_lrec[recp + u];
+                    const uint32_t U = splat_byte<0>(rec.x), U0 = splat_byte<1>(rec.x), U1 = splat_byte<2>(rec.x);
+                    const uint32_t R = splat_byte<0>(rec.y), R0 = splat_byte<1>(rec.y), R1 = splat_byte<2>(rec.y);
+                    const uint32_t *old = ring_lane + ((u - bs) & (RS_T - 1)) * 64 * NP;  // column j + u - bs
+                    Pack<NP> o;
+#pragma unroll
+                    for (int i = 0; i < NP; i++) {
+                        const uint32_t a = bt_pair(U, U0, U1, w[0][i], w[1][i], w[2][i]);
+                        const uint32_t b = bt_pair(R, R0, R1, w[3][i], w[4][i], w[5][i]);
+                        const uint32_t pix = pk_add(a, pk_shr_u(b, 2));
+                        hs[i] = pk_sub(pk_add(hs[i], pix), old[i]);
+                        ring_lane_w[u * 64 * NP + i] = pix;
+                        o.r[i] = hs[i];
+                    }
+                    buf_store<NP>(o, orow, voff, so);
+                    so += pxb;
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) tap[c] -= RS_T;
+                recp += RS_T;
+            }
+            next_x = j - SW2;
+        }
     }
+    for (; j <= j1; j++) column(j);
 }
 
 // C(y) = sum_{j=-SH2..SH2} hsum(clamp(y+j, 0, H-1)), running along y inside a band of rows.

@@ -333,16 +333,27 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             dim3 grid((unsigned)((int64_t)H * nchunks)), block(64);
             const uint2 *lrec = (const uint2 *)e->lrec.p;
             const uint8_t *rpl = (const uint8_t *)e->rplanes.p;
-            if (g.NP == 1) {
-                if (l.total_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_hsum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, l.total_bytes));
-                hipLaunchKernelGGL(k_hsum<1>, grid, block, l.total_bytes, st, g, lrec, rpl, HS, XL, nchunks, RS, l.ring_bytes, l.lrec_bytes, l.seg_len);
-            } else if (g.NP == 2) {
-                if (l.total_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_hsum<2>, hipFuncAttributeMaxDynamicSharedMemorySize, l.total_bytes));
-                hipLaunchKernelGGL(k_hsum<2>, grid, block, l.total_bytes, st, g, lrec, rpl, HS, XL, nchunks, RS, l.ring_bytes, l.lrec_bytes, l.seg_len);
-            } else {
-                if (l.total_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_hsum<4>, hipFuncAttributeMaxDynamicSharedMemorySize, l.total_bytes));
-                hipLaunchKernelGGL(k_hsum<4>, grid, block, l.total_bytes, st, g, lrec, rpl, HS, XL, nchunks, RS, l.ring_bytes, l.lrec_bytes, l.seg_len);
-            }
+            // RS_T = RS instantiations carry the unrolled interior fast path (block sizes up to 15)
+#define SGM_HSUM(NP_, RS_)                                                                                          \
+    do {                                                                                                            \
+        if (l.total_bytes > 48 * 1024)                                                                              \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_hsum<NP_, RS_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        l.total_bytes));                                                            \
+        hipLaunchKernelGGL((k_hsum<NP_, RS_>), grid, block, l.total_bytes, st, g, lrec, rpl, HS, XL, nchunks, RS,    \
+                           l.ring_bytes, l.lrec_bytes, l.seg_len);                                                  \
+    } while (0)
+#define SGM_HSUM_NP(NP_)                    \
+    do {                                    \
+        if (RS == 4) SGM_HSUM(NP_, 4);      \
+        else if (RS == 8) SGM_HSUM(NP_, 8); \
+        else if (RS == 16) SGM_HSUM(NP_, 16); \
+        else SGM_HSUM(NP_, 0);              \
+    } while (0)
+            if (g.NP == 1) SGM_HSUM_NP(1);
+            else if (g.NP == 2) SGM_HSUM_NP(2);
+            else SGM_HSUM_NP(4);
+#undef SGM_HSUM_NP
+#undef SGM_HSUM
             KCHECK();
         }
         if ((rc = stage_end(e, 1))) return rc;
