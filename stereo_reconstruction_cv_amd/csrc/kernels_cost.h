@@ -313,40 +313,76 @@ __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, in
 // Same vertical box sum, each hsum row read ONCE: the last 2*SH2+2 rows of the column live in a
 // register ring (statically indexed: bands start at multiples of RS and the row loop is unrolled
 // by RS).  Instantiated for the common block sizes; other sizes use k_vsum.
-template <int SH2_>
+template <int SH2_, int NW /* dwords per thread: 2 or 4 */>
 __global__ __launch_bounds__(256) void k_vsum_ring(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
                                                    int H, int64_t rowsz, int RB /* multiple of RS */)
 {
     constexpr int RS = SH2_ <= 1 ? 4 : (SH2_ <= 3 ? 8 : (SH2_ <= 7 ? 16 : 32));  // pow2 >= 2*SH2+2
-    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // 4 int16 per thread
+    typedef Pack<NW> V;
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (2 * NW);  // 2*NW int16 per thread
     if (e >= rowsz) return;
     const int y0 = blockIdx.y * RB, y1 = min(y0 + RB, H);
-    uint2 ring[RS];
-    uint2 acc = make_uint2(0, 0);
-    auto ld = [&](int r) { return *reinterpret_cast<const uint2 *>(hs + (int64_t)min(max(r, 0), H - 1) * rowsz + e); };
+    V ring[RS];
+    V acc;
+    acc.fill(0);
+    auto ld = [&](int r) {
+        V v;
+        v.load(hs + (int64_t)min(max(r, 0), H - 1) * rowsz + e);
+        return v;
+    };
+    auto step = [&](const V &v, int u, int y) {  // row y = yb + u enters its window's new bottom row v
+        const V &o = ring[(u - SH2_ - 1) & (RS - 1)];
+#pragma unroll
+        for (int i = 0; i < NW; i++) acc.r[i] = pk_sub(pk_add(acc.r[i], v.r[i]), o.r[i]);
+        ring[(u + SH2_) & (RS - 1)] = v;
+        acc.store(C + (int64_t)y * rowsz + e);
+    };
     // window of row y0: rows y0-SH2 .. y0+SH2 (y0 % RS == 0, so slot(y0 + j) = j & (RS-1) is static)
 #pragma unroll
     for (int j = -SH2_; j <= SH2_; j++) {
-        const uint2 v = ld(y0 + j);
+        const V v = ld(y0 + j);
         ring[j & (RS - 1)] = v;
-        acc.x = pk_add(acc.x, v.x);
-        acc.y = pk_add(acc.y, v.y);
+#pragma unroll
+        for (int i = 0; i < NW; i++) acc.r[i] = pk_add(acc.r[i], v.r[i]);
     }
-    *reinterpret_cast<uint2 *>(C + (int64_t)y0 * rowsz + e) = acc;
-    for (int yb = y0; yb < y1; yb += RS) {
+    acc.store(C + (int64_t)y0 * rowsz + e);
+    // a guarded block of RS rows (band edges, rows whose incoming tap is clamped)
+    auto block_slow = [&](int yb) {
 #pragma unroll
         for (int u = 0; u < RS; u++) {
             const int y = yb + u;
-            if (y > y0 && y < y1) {
-                const uint2 v = ld(y + SH2_);
-                const uint2 o = ring[(u - SH2_ - 1) & (RS - 1)];
-                acc.x = pk_sub(pk_add(acc.x, v.x), o.x);
-                acc.y = pk_sub(pk_add(acc.y, v.y), o.y);
-                ring[(u + SH2_) & (RS - 1)] = v;
-                *reinterpret_cast<uint2 *>(C + (int64_t)y * rowsz + e) = acc;
-            }
+            if (y > y0 && y < y1) step(ld(y + SH2_), u, y);
         }
+    };
+    // fast blocks: all RS rows inside the band, no clamped tap.  Their loads are issued a whole
+    // block ahead and the loop body is straight-line, so the loads stay in flight across the
+    // arithmetic and stores of the previous block (a branch between issue and use would make
+    // hipcc wait for vmcnt(0)).
+    auto fast = [&](int yb) { return yb > y0 && yb + RS <= y1 && yb + RS - 1 + SH2_ <= H - 1; };
+    auto block_load = [&](V *v, int yb) {
+#pragma unroll
+        for (int u = 0; u < RS; u++) v[u].load(hs + (int64_t)(yb + u + SH2_) * rowsz + e);
+    };
+    auto block_fast = [&](const V *v, int yb) {
+#pragma unroll
+        for (int u = 0; u < RS; u++) step(v[u], u, yb + u);
+    };
+    int yb = y0;
+    block_slow(yb);
+    yb += RS;
+    if (fast(yb)) {
+        V vA[RS], vB[RS];
+        block_load(vA, yb);
+        for (; fast(yb + RS) && fast(yb + 2 * RS); yb += 2 * RS) {
+            block_load(vB, yb + RS);
+            block_fast(vA, yb);
+            block_load(vA, yb + 2 * RS);
+            block_fast(vB, yb + RS);
+        }
+        block_fast(vA, yb);
+        yb += RS;
     }
+    for (; yb < y1; yb += RS) block_slow(yb);
 }
 
 }  // namespace sgm

@@ -364,13 +364,21 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             const int RB = 96;  // multiple of every ring size used below
             const int16_t *hsp = (const int16_t *)HS;
             int16_t *cp = (int16_t *)e->cost.p;
-            dim3 block(256), gridr((unsigned)((g.rowsz / 4 + 255) / 256), (H + RB - 1) / RB);
+            const bool wide = !(e->debug & 8);  // 8 int16 per thread (debug 8: 4, for A/B timing)
+            const int per_thread = wide ? 8 : 4;
+            dim3 block(256), gridr((unsigned)((g.rowsz / per_thread + 255) / 256), (H + RB - 1) / RB);
+#define SGM_VSUM(SH2_)                                                                                      \
+    case SH2_:                                                                                              \
+        if (wide) hipLaunchKernelGGL((k_vsum_ring<SH2_, 4>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); \
+        else hipLaunchKernelGGL((k_vsum_ring<SH2_, 2>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB);      \
+        break;
             switch (g.SH2) {  // ring variant: each hsum row is read once
-            case 1: hipLaunchKernelGGL(k_vsum_ring<1>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
-            case 2: hipLaunchKernelGGL(k_vsum_ring<2>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
-            case 3: hipLaunchKernelGGL(k_vsum_ring<3>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
-            case 4: hipLaunchKernelGGL(k_vsum_ring<4>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
-            case 5: hipLaunchKernelGGL(k_vsum_ring<5>, gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); break;
+                SGM_VSUM(1)
+                SGM_VSUM(2)
+                SGM_VSUM(3)
+                SGM_VSUM(4)
+                SGM_VSUM(5)
+#undef SGM_VSUM
             default: {
                 dim3 grid((unsigned)((g.rowsz / 8 + 255) / 256), (H + 63) / 64);
                 hipLaunchKernelGGL(k_vsum, grid, block, 0, st, hsp, cp, H, g.rowsz, g.SH2, 64);
