@@ -17,6 +17,11 @@
  *   sgm_compact_points   <- valid_points = points_3D[mask]; valid_colors = colors[mask]
  *                           (ordered compaction + colour gather)                main.ipynb:726-737
  *   sgm_pipeline_device  <- cell c13: compute -> scale/mask -> reproject       main.ipynb:781,790
+ *   sgm_init_undistort_rectify_map
+ *                        <- cv2.initUndistortRectifyMap(K, None, R1, P1, size, cv2.CV_32F)
+ *                                                                    gui.py:160-161, main.ipynb cell 7
+ *   sgm_remap_linear_u8  <- cv2.remap(img, map1, map2, interpolation=cv2.INTER_LINEAR)
+ *                                                                    gui.py:163-164, main.ipynb cell 7
  *   sgm_compute_batch    <- the same, over N independent pairs (frame sharding unit)
  *
  * Conventions: plain pointers and sizes, no C++ types, no exceptions across the boundary.
@@ -121,6 +126,18 @@ int sgm_filter_speckles(sgm_engine *e, int16_t *img /* in place */, int H, int W
                         int maxSpeckleSize, int maxDiff);
 int sgm_get_tap(sgm_engine *e, int tap, void *host_dst, int64_t bytes);
 
+/* Rectification in front of the path.
+ * K: 3x3 row-major.  dist: NULL or ndist in {4,5,8,12} coefficients (k1 k2 p1 p2 [k3 [k4 k5 k6
+ * [s1 s2 s3 s4]]]); 14 (tilt) -> SGM_ERR_UNSUPPORTED.  R: 3x3 or NULL (identity).  P: 3x3
+ * (pcols 3) / 3x4 (pcols 4) or NULL (= K).  map1/map2: [H][W] float32 (the CV_32FC1 map pair). */
+int sgm_init_undistort_rectify_map(sgm_engine *e, const double K[9], const double *dist, int ndist,
+                                   const double *R, const double *P, int pcols, int W, int H,
+                                   float *map1_out, float *map2_out);
+/* INTER_LINEAR, BORDER_CONSTANT with borderValue 0; src [sH][sW][cn] uint8 (cn 1..4, row stride
+ * sstride bytes), maps [dH][dW] float32, dst [dH][dW][cn] dense. */
+int sgm_remap_linear_u8(sgm_engine *e, const uint8_t *src, int sH, int sW, int64_t sstride, int cn,
+                        const float *map1, const float *map2, int dH, int dW, uint8_t *dst);
+
 /* ---- device-pointer entry points (asynchronous on the engine's stream) ---- */
 int sgm_compute_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W,
                        int64_t stride_bytes, void *d_disp_i16);
@@ -134,6 +151,12 @@ int sgm_compact_points_device(sgm_engine *e, const void *d_xyz, const void *d_di
                               const void *d_colors_rgb, int64_t n, void *d_out_points,
                               void *d_out_colors, int64_t *n_valid);
 /* cell c13 in one call: disparity (int16) -> float disparity -> XYZ; any output may be NULL */
+int sgm_init_undistort_rectify_map_device(sgm_engine *e, const double K[9], const double *dist, int ndist,
+                                          const double *R, const double *P, int pcols, int W, int H,
+                                          void *d_map1_f32, void *d_map2_f32);
+int sgm_remap_linear_u8_device(sgm_engine *e, const void *d_src, int sH, int sW, int64_t sstride, int cn,
+                               const void *d_map1_f32, const void *d_map2_f32, int dH, int dW, void *d_dst,
+                               int64_t dstride);
 int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W,
                         int64_t stride_bytes, const double Q[16], void *d_disp_i16,
                         void *d_disp_f32, void *d_xyz_f32);

@@ -29,7 +29,7 @@ class Taps(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("sgbm_oracle.c", "sgbm_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("sgbm_oracle.c", "sgbm_oracle.h", "rectify_oracle.c", "rectify_oracle.h")]
     stale = (not os.path.exists(_SO)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
@@ -58,6 +58,14 @@ def lib():
         L.oracle_reproject_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                            C.c_void_p]
         L.oracle_valid_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_invert3x3.restype = C.c_int
+        L.oracle_invert3x3.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_init_undistort_rectify_map.restype = C.c_int
+        L.oracle_init_undistort_rectify_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_remap_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_bilinear_tab_i16.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -163,3 +171,49 @@ def valid_mask(xyz: np.ndarray, disp: np.ndarray) -> np.ndarray:
     out = np.empty(disp.shape, np.uint8)
     lib().oracle_valid_mask(xyz.ctypes.data, disp.ctypes.data, disp.size, out.ctypes.data)
     return out.astype(bool)
+
+
+# ---- rectification step in front of the path (rectify_oracle.h; gui.py:160-164) ----
+
+def invert3x3(m: np.ndarray) -> np.ndarray:
+    m = np.ascontiguousarray(m, dtype=np.float64).reshape(3, 3)
+    out = np.zeros((3, 3), np.float64)
+    lib().oracle_invert3x3(m.ctypes.data, out.ctypes.data)
+    return out
+
+
+def init_undistort_rectify_map(K, dist, R, P, size):
+    """cv2.initUndistortRectifyMap(K, dist, R, P, (W, H), cv2.CV_32FC1) -> (map1, map2)."""
+    W, H = int(size[0]), int(size[1])
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+    d = None if dist is None else np.ascontiguousarray(dist, dtype=np.float64).ravel()
+    Rm = None if R is None else np.ascontiguousarray(R, dtype=np.float64).reshape(3, 3)
+    Pm = None if P is None else np.ascontiguousarray(P, dtype=np.float64)
+    m1 = np.empty((H, W), np.float32)
+    m2 = np.empty((H, W), np.float32)
+    rc = lib().oracle_init_undistort_rectify_map(
+        K.ctypes.data, None if d is None else d.ctypes.data, 0 if d is None else d.size,
+        None if Rm is None else Rm.ctypes.data, None if Pm is None else Pm.ctypes.data,
+        0 if Pm is None else Pm.shape[1], W, H, m1.ctypes.data, m2.ctypes.data)
+    if rc != 0:
+        raise ValueError("oracle_init_undistort_rectify_map: unsupported arguments or singular P*R")
+    return m1, m2
+
+
+def remap_linear(src: np.ndarray, map1: np.ndarray, map2: np.ndarray) -> np.ndarray:
+    """cv2.remap(src, map1, map2, cv2.INTER_LINEAR) for uint8 images (H, W) or (H, W, cn)."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    map1 = np.ascontiguousarray(map1, dtype=np.float32)
+    map2 = np.ascontiguousarray(map2, dtype=np.float32)
+    dH, dW = map1.shape
+    out = np.empty((dH, dW) if src.ndim == 2 else (dH, dW, cn), np.uint8)
+    lib().oracle_remap_linear_u8(src.ctypes.data, src.shape[0], src.shape[1], src.strides[0], cn,
+                                 map1.ctypes.data, map2.ctypes.data, dH, dW, out.ctypes.data)
+    return out
+
+
+def bilinear_tab() -> np.ndarray:
+    t = np.empty((32, 32, 4), np.int16)
+    lib().oracle_bilinear_tab_i16(t.ctypes.data)
+    return t

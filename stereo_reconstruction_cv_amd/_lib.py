@@ -25,6 +25,8 @@ EXPORTS = (
     "sgm_compact_points_device", "sgm_compute_device",
     "sgm_disp_to_float_device", "sgm_reproject_device", "sgm_valid_mask_device",
     "sgm_pipeline_device", "sgm_synchronize", "sgm_get_stage_times", "sgm_algorithmic_bytes",
+    "sgm_init_undistort_rectify_map", "sgm_init_undistort_rectify_map_device",
+    "sgm_remap_linear_u8", "sgm_remap_linear_u8_device",
 )
 
 
@@ -85,6 +87,10 @@ def load():
     L.sgm_get_stage_times.argtypes = [vp, C.POINTER(SgmStageTimes)]
     L.sgm_algorithmic_bytes.argtypes = [pp, i32, i32, i32]
     L.sgm_algorithmic_bytes.restype = i64
+    L.sgm_init_undistort_rectify_map.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]
+    L.sgm_init_undistort_rectify_map_device.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]
+    L.sgm_remap_linear_u8.argtypes = [vp, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp]
+    L.sgm_remap_linear_u8_device.argtypes = [vp, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i64]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("sgm_abi_version", "sgm_device_count"):

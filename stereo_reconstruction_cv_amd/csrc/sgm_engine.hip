@@ -17,6 +17,7 @@
 #include "kernels_cost.h"
 #include "kernels_path.h"
 #include "kernels_post.h"
+#include "kernels_rectify.h"
 #include "kernels_sweep.h"
 
 using namespace sgm;
@@ -94,6 +95,7 @@ struct sgm_engine {
     DevBuf disp_raw, disp_med, disp_out;  // int16 [H][W]
     DevBuf label, csize, rlen;          // int32 [H][W] each
     DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
+    DevBuf rmap1, rmap2, rsrc, rdst;    // host-pointer rectification stages
     DevBuf ccount, cpts, crgb, crgb_in; // point compaction
 
     // profiling
@@ -624,7 +626,7 @@ void sgm_destroy(sgm_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->wta, &e->bndL, &e->bndL2,
+    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
                       &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in};
     for (DevBuf *b : bufs) b->release();
@@ -687,6 +689,123 @@ int sgm_valid_mask_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f
     hipLaunchKernelGGL(k_valid_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const float *)d_xyz,
                        (const float *)d_disp_f32, n, (uint8_t *)d_mask_u8);
     KCHECK();
+    return SGM_OK;
+}
+
+// ---- rectification in front of the path (gui.py:160-164) ----------------------------------------
+
+// (P[:, :3] * R)^-1 in double, the closed form cv::invert uses for 3x3 (lapack.cpp)
+static bool rectify_inverse(const double K[9], const double *R, const double *P, int pcols, double ir[9])
+{
+    double A[9], Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, M[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) A[r * 3 + c] = P ? P[r * pcols + c] : K[r * 3 + c];
+    if (R) memcpy(Rm, R, sizeof(Rm));
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int q = 0; q < 3; q++) s += A[r * 3 + q] * Rm[q * 3 + c];
+            M[r * 3 + c] = s;
+        }
+    const double m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[3], m11 = M[4], m12 = M[5], m20 = M[6], m21 = M[7], m22 = M[8];
+    double d = m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
+    if (d == 0.) return false;
+    d = 1. / d;
+    ir[0] = (m11 * m22 - m12 * m21) * d;
+    ir[1] = (m02 * m21 - m01 * m22) * d;
+    ir[2] = (m01 * m12 - m02 * m11) * d;
+    ir[3] = (m12 * m20 - m10 * m22) * d;
+    ir[4] = (m00 * m22 - m02 * m20) * d;
+    ir[5] = (m02 * m10 - m00 * m12) * d;
+    ir[6] = (m10 * m21 - m11 * m20) * d;
+    ir[7] = (m01 * m20 - m00 * m21) * d;
+    ir[8] = (m00 * m11 - m01 * m10) * d;
+    return true;
+}
+
+int sgm_init_undistort_rectify_map_device(sgm_engine *e, const double K[9], const double *dist, int ndist,
+                                          const double *R, const double *P, int pcols, int W, int H,
+                                          void *d_map1_f32, void *d_map2_f32)
+{
+    if (!e || !K || !d_map1_f32 || !d_map2_f32 || W <= 0 || H <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (P && pcols != 3 && pcols != 4) return set_err(SGM_ERR_INVALID_ARG, "newCameraMatrix must be 3x3 or 3x4");
+    RectifyArgs a;
+    memset(&a, 0, sizeof(a));
+    if (dist) {
+        if (ndist == 14) return set_err(SGM_ERR_UNSUPPORTED, "tilted-sensor distortion terms are not supported");
+        if (ndist != 4 && ndist != 5 && ndist != 8 && ndist != 12)
+            return set_err(SGM_ERR_INVALID_ARG, "distCoeffs must hold 4, 5, 8 or 12 values");
+        for (int i = 0; i < ndist; i++) a.k[i] = dist[i];
+    }
+    if (!rectify_inverse(K, R, P, pcols, a.ir)) return set_err(SGM_ERR_INVALID_ARG, "newCameraMatrix * R is singular");
+    a.fx = K[0];
+    a.fy = K[4];
+    a.u0 = K[2];
+    a.v0 = K[5];
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_rectify_map, dim3((H + 63) / 64), dim3(64), 0, e->stream, a, W, H, (float *)d_map1_f32, (float *)d_map2_f32);
+    KCHECK();
+    return SGM_OK;
+}
+
+int sgm_init_undistort_rectify_map(sgm_engine *e, const double K[9], const double *dist, int ndist, const double *R,
+                                   const double *P, int pcols, int W, int H, float *map1_out, float *map2_out)
+{
+    if (!e || !map1_out || !map2_out || W <= 0 || H <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    const size_t bytes = (size_t)W * H * 4;
+    int rc;
+    HIP_TRY(hipSetDevice(e->device));
+    if ((rc = e->rmap1.ensure(bytes)) || (rc = e->rmap2.ensure(bytes))) return rc;
+    if ((rc = sgm_init_undistort_rectify_map_device(e, K, dist, ndist, R, P, pcols, W, H, e->rmap1.p, e->rmap2.p))) return rc;
+    HIP_TRY(hipMemcpyAsync(map1_out, e->rmap1.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(map2_out, e->rmap2.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SGM_OK;
+}
+
+int sgm_remap_linear_u8_device(sgm_engine *e, const void *d_src, int sH, int sW, int64_t sstride, int cn,
+                               const void *d_map1_f32, const void *d_map2_f32, int dH, int dW, void *d_dst,
+                               int64_t dstride)
+{
+    if (!e || !d_src || !d_map1_f32 || !d_map2_f32 || !d_dst || sH <= 0 || sW <= 0 || dH <= 0 || dW <= 0)
+        return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (cn < 1 || cn > 4) return set_err(SGM_ERR_UNSUPPORTED, "remap supports 1..4 interleaved 8-bit channels, got %d", cn);
+    if (sstride < (int64_t)sW * cn || dstride < (int64_t)dW * cn) return set_err(SGM_ERR_INVALID_ARG, "stride smaller than a row");
+    if (sH > 32767 || sW > 32767) return set_err(SGM_ERR_UNSUPPORTED, "source larger than 32767 pixels (upstream's int16 coordinates)");
+    HIP_TRY(hipSetDevice(e->device));
+    dim3 grid((dW + 255) / 256, dH), block(256);
+    const uint8_t *s = (const uint8_t *)d_src;
+    const float *m1 = (const float *)d_map1_f32, *m2 = (const float *)d_map2_f32;
+    uint8_t *d = (uint8_t *)d_dst;
+    switch (cn) {
+    case 1: hipLaunchKernelGGL(k_remap_linear<1>, grid, block, 0, e->stream, s, sH, sW, sstride, m1, m2, dH, dW, d, dstride); break;
+    case 2: hipLaunchKernelGGL(k_remap_linear<2>, grid, block, 0, e->stream, s, sH, sW, sstride, m1, m2, dH, dW, d, dstride); break;
+    case 3: hipLaunchKernelGGL(k_remap_linear<3>, grid, block, 0, e->stream, s, sH, sW, sstride, m1, m2, dH, dW, d, dstride); break;
+    default: hipLaunchKernelGGL(k_remap_linear<4>, grid, block, 0, e->stream, s, sH, sW, sstride, m1, m2, dH, dW, d, dstride); break;
+    }
+    KCHECK();
+    return SGM_OK;
+}
+
+int sgm_remap_linear_u8(sgm_engine *e, const uint8_t *src, int sH, int sW, int64_t sstride, int cn, const float *map1,
+                        const float *map2, int dH, int dW, uint8_t *dst)
+{
+    if (!e || !src || !map1 || !map2 || !dst || sH <= 0 || sW <= 0 || dH <= 0 || dW <= 0)
+        return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (cn < 1 || cn > 4) return set_err(SGM_ERR_UNSUPPORTED, "remap supports 1..4 interleaved 8-bit channels, got %d", cn);
+    if (sstride < (int64_t)sW * cn) return set_err(SGM_ERR_INVALID_ARG, "stride smaller than a row");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t sbytes = (size_t)sH * sW * cn, mbytes = (size_t)dH * dW * 4, dbytes = (size_t)dH * dW * cn;
+    int rc;
+    if ((rc = e->rsrc.ensure(sbytes)) || (rc = e->rmap1.ensure(mbytes)) || (rc = e->rmap2.ensure(mbytes)) || (rc = e->rdst.ensure(dbytes)))
+        return rc;
+    HIP_TRY(hipMemcpy2DAsync(e->rsrc.p, (size_t)sW * cn, src, (size_t)sstride, (size_t)sW * cn, sH, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->rmap1.p, map1, mbytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->rmap2.p, map2, mbytes, hipMemcpyHostToDevice, e->stream));
+    if ((rc = sgm_remap_linear_u8_device(e, e->rsrc.p, sH, sW, (int64_t)sW * cn, cn, e->rmap1.p, e->rmap2.p, dH, dW, e->rdst.p, (int64_t)dW * cn)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(dst, e->rdst.p, dbytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return SGM_OK;
 }
 

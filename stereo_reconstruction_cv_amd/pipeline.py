@@ -68,3 +68,13 @@ def run_disparity(imgL, imgR, Q, ndisp=16, mindis=0):
     points_3D = reconstruct_3D(disparity_map, Q)
     mask = valid_point_mask(points_3D, disparity_map) if points_3D is not None else None
     return disparity_map, points_3D, mask
+
+
+def rectify_pair(imgL, imgR, K0, K1, R1, R2, P1, P2, image_size):
+    """The rectify block of main.ipynb cell 7 / gui.py:160-164: two float map pairs from the
+    stereoRectify outputs, then a bilinear remap of both views.  Returns (imgL_rect, imgR_rect)."""
+    mapL1, mapL2 = _cv.initUndistortRectifyMap(K0, None, R1, P1, image_size, _cv.CV_32F)
+    mapR1, mapR2 = _cv.initUndistortRectifyMap(K1, None, R2, P2, image_size, _cv.CV_32F)
+    imgL_rect = _cv.remap(imgL, mapL1, mapL2, interpolation=_cv.INTER_LINEAR)
+    imgR_rect = _cv.remap(imgR, mapR1, mapR2, interpolation=_cv.INTER_LINEAR)
+    return imgL_rect, imgR_rect

@@ -198,6 +198,46 @@ class Engine:
         Q = np.ascontiguousarray(Q, np.float64)
         _check(self._L.sgm_reproject_device(self._h, d_disp, H, W, Q.ctypes.data, int(handle_missing), d_xyz))
 
+    # -- rectification in front of the path (gui.py:160-164) --
+    @staticmethod
+    def _rectify_args(K, dist, R, P):
+        K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+        d = None if dist is None else np.ascontiguousarray(dist, np.float64).ravel()
+        Rm = None if R is None else np.ascontiguousarray(R, np.float64).reshape(3, 3)
+        Pm = None if P is None else np.ascontiguousarray(P, np.float64)
+        if Pm is not None and Pm.shape not in ((3, 3), (3, 4)):
+            raise error("initUndistortRectifyMap: newCameraMatrix must be 3x3 or 3x4")
+        return K, d, Rm, Pm
+
+    def init_undistort_rectify_map_host(self, K, dist, R, P, W: int, H: int):
+        K, d, Rm, Pm = self._rectify_args(K, dist, R, P)
+        m1 = np.empty((H, W), np.float32)
+        m2 = np.empty((H, W), np.float32)
+        _check(self._L.sgm_init_undistort_rectify_map(
+            self._h, K.ctypes.data, None if d is None else d.ctypes.data, 0 if d is None else d.size,
+            None if Rm is None else Rm.ctypes.data, None if Pm is None else Pm.ctypes.data,
+            0 if Pm is None else Pm.shape[1], W, H, m1.ctypes.data, m2.ctypes.data))
+        return m1, m2
+
+    def init_undistort_rectify_map_device(self, K, dist, R, P, W: int, H: int, d_map1: int, d_map2: int) -> None:
+        K, d, Rm, Pm = self._rectify_args(K, dist, R, P)
+        _check(self._L.sgm_init_undistort_rectify_map_device(
+            self._h, K.ctypes.data, None if d is None else d.ctypes.data, 0 if d is None else d.size,
+            None if Rm is None else Rm.ctypes.data, None if Pm is None else Pm.ctypes.data,
+            0 if Pm is None else Pm.shape[1], W, H, d_map1, d_map2))
+
+    def remap_linear_host(self, src: np.ndarray, map1: np.ndarray, map2: np.ndarray) -> np.ndarray:
+        cn = 1 if src.ndim == 2 else src.shape[2]
+        dH, dW = map1.shape
+        out = np.empty((dH, dW) if src.ndim == 2 else (dH, dW, cn), np.uint8)
+        _check(self._L.sgm_remap_linear_u8(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0], cn,
+                                           map1.ctypes.data, map2.ctypes.data, dH, dW, out.ctypes.data))
+        return out
+
+    def remap_linear_device(self, d_src: int, sH: int, sW: int, sstride: int, cn: int, d_map1: int, d_map2: int,
+                            dH: int, dW: int, d_dst: int, dstride: int) -> None:
+        _check(self._L.sgm_remap_linear_u8_device(self._h, d_src, sH, sW, sstride, cn, d_map1, d_map2, dH, dW, d_dst, dstride))
+
     def valid_mask_device(self, d_xyz: int, d_disp: int, n: int, d_mask: int) -> None:
         _check(self._L.sgm_valid_mask_device(self._h, d_xyz, d_disp, n, d_mask))
 
@@ -338,3 +378,51 @@ def reprojectImageTo3D(disparity, Q, _3dImage=None, handleMissingValues=False, d
         raise error("reprojectImageTo3D: empty disparity")
     d = np.ascontiguousarray(d, np.float32)
     return get_engine(_DEFAULT).reproject_host(d, Q, bool(handleMissingValues))
+
+
+# ---- rectification in front of the path (gui.py:160-164, main.ipynb cell 7) ----
+CV_32FC1 = 5
+CV_16SC2 = 11
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
+BORDER_CONSTANT = 0
+
+
+def initUndistortRectifyMap(cameraMatrix, distCoeffs, R, newCameraMatrix, size, m1type, map1=None, map2=None):
+    """(map1, map2) float32 (H, W) source coordinates for every destination pixel
+    (cv2.initUndistortRectifyMap(K0, None, R1, P1, image_size, cv2.CV_32F), gui.py:160)."""
+    if m1type not in (CV_32F, CV_32FC1):
+        raise error("initUndistortRectifyMap: only m1type=CV_32FC1 (two float maps, what the reference asks for) is implemented")
+    W, H = int(size[0]), int(size[1])
+    if W <= 0 or H <= 0:
+        raise error("initUndistortRectifyMap: (-215:Assertion failed) size.width > 0 && size.height > 0")
+    K = np.asarray(cameraMatrix)
+    if K.shape != (3, 3):
+        raise error("initUndistortRectifyMap: (-215:Assertion failed) A.size() == Size(3,3)")
+    if distCoeffs is not None and np.asarray(distCoeffs).size == 0:
+        distCoeffs = None
+    if distCoeffs is not None and np.asarray(distCoeffs).size not in (4, 5, 8, 12, 14):
+        raise error("initUndistortRectifyMap: (-215:Assertion failed) distCoeffs must hold 4, 5, 8, 12 or 14 values")
+    if R is not None and np.asarray(R).size == 0:
+        R = None
+    if R is not None and np.asarray(R).shape != (3, 3):
+        raise error("initUndistortRectifyMap: (-215:Assertion failed) R.size() == Size(3,3)")
+    if newCameraMatrix is not None and np.asarray(newCameraMatrix).size == 0:
+        newCameraMatrix = None
+    return get_engine(_DEFAULT).init_undistort_rectify_map_host(K, distCoeffs, R, newCameraMatrix, W, H)
+
+
+def remap(src, map1, map2, interpolation, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
+    """Bilinear gather of an 8-bit image through a float map pair
+    (cv2.remap(imgL, mapL1, mapL2, interpolation=cv2.INTER_LINEAR), gui.py:163)."""
+    if interpolation != INTER_LINEAR:
+        raise error("remap: only interpolation=INTER_LINEAR (what the reference uses) is implemented")
+    if borderMode != BORDER_CONSTANT or np.any(np.asarray(borderValue) != 0):
+        raise error("remap: only borderMode=BORDER_CONSTANT with borderValue=0 (the defaults) is implemented")
+    s = np.asarray(src)
+    if s.dtype != np.uint8 or s.ndim not in (2, 3) or (s.ndim == 3 and not 1 <= s.shape[2] <= 4) or s.size == 0:
+        raise error("remap: source must be a non-empty uint8 image with 1..4 channels")
+    m1, m2 = np.asarray(map1), np.asarray(map2)
+    if m1.dtype != np.float32 or m2.dtype != np.float32 or m1.ndim != 2 or m1.shape != m2.shape or m1.size == 0:
+        raise error("remap: (-215:Assertion failed) map1 and map2 must be CV_32FC1 of the same size")
+    s = np.ascontiguousarray(s)
+    return get_engine(_DEFAULT).remap_linear_host(s, np.ascontiguousarray(m1), np.ascontiguousarray(m2))

@@ -45,3 +45,37 @@ def test_hip_reproduces_golden(name):
     want = G[f"{name}/xyz"]
     fin = np.isfinite(want)
     assert np.array_equal(np.isfinite(xyz), fin) and np.allclose(xyz[fin], want[fin], rtol=1e-4, atol=0)
+
+
+# ---- rectification step (tests/golden/rectify_golden.npz, made by make_rectify_golden.py) ----
+RG = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rectify_golden.npz"))
+RNAMES = sorted({k.split("/")[0] for k in RG.files})
+
+
+def _rect_args(name):
+    opt = lambda a: None if a.size == 0 else a
+    return RG[f"{name}/K"], opt(RG[f"{name}/dist"]), opt(RG[f"{name}/R"]), opt(RG[f"{name}/P"]), tuple(int(v) for v in RG[f"{name}/size"])
+
+
+def _check_rect(name, m1, m2, remap):
+    W, H = (int(v) for v in RG[f"{name}/size"])
+    assert hashlib.sha256(m1.tobytes()).digest() == RG[f"{name}/sha_map1"].tobytes()
+    assert hashlib.sha256(m2.tobytes()).digest() == RG[f"{name}/sha_map2"].tobytes()
+    assert np.array_equal(m1[[0, H - 1]], RG[f"{name}/map1_rows"]) and np.array_equal(m2[[0, H - 1]], RG[f"{name}/map2_rows"])
+    for cn in (1, 3):
+        assert np.array_equal(remap(RG[f"{name}/img{cn}"], m1, m2), RG[f"{name}/remap{cn}"])
+
+
+@pytest.mark.parametrize("name", RNAMES)
+def test_oracle_reproduces_rectify_golden(name):
+    m1, m2 = O.init_undistort_rectify_map(*_rect_args(name))
+    _check_rect(name, m1, m2, O.remap_linear)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", RNAMES)
+def test_hip_reproduces_rectify_golden(name):
+    import stereo_reconstruction_cv_amd as cv
+    K, dist, R, P, size = _rect_args(name)
+    m1, m2 = cv.initUndistortRectifyMap(K, dist, R, P, size, cv.CV_32FC1)
+    _check_rect(name, m1, m2, lambda img, a, b: cv.remap(img, a, b, cv.INTER_LINEAR))
