@@ -38,13 +38,23 @@ struct ShiftRegs {
     uint32_t up = SGM_SENT, dn = SGM_SENT;
 };
 
-template <int NP, bool PARTIAL>
+// Lane groups (GW < 64, several pixels per wave): first / last say whether this lane is the first /
+// last of its group; those lanes must see the sentinel, not the neighbouring group's value.
+struct GroupEdge {
+    bool first = false, last = false;
+};
+template <int NP, bool PARTIAL, int GW = 64>
 __device__ __forceinline__ void path_elem(const Pack<NP> &Cp, const Pack<NP> &Lq, uint32_t P1s, uint32_t P2s,
-                                          bool active, Pack<NP> &Ln, uint32_t &rmin, ShiftRegs &sr)
+                                          bool active, Pack<NP> &Ln, uint32_t &rmin, ShiftRegs &sr,
+                                          GroupEdge ge = GroupEdge())
 {
     sr.up = from_lower_lane(Lq.r[NP - 1], sr.up);
     sr.dn = from_upper_lane(Lq.r[0], sr.dn);
-    const uint32_t up = sr.up, dn = sr.dn;
+    uint32_t up = sr.up, dn = sr.dn;
+    if (GW < 64) {
+        up = ge.first ? SGM_SENT : up;
+        dn = ge.last ? SGM_SENT : dn;
+    }
     rmin = SGM_SENT;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -87,7 +97,9 @@ __device__ __forceinline__ void path_normalise(const Pack<NP> &Ln, uint32_t m, b
 // the literal per-element form.
 // N pixels at a time (their reduction chains interleave; see wave_min_pk_n).  All stores come
 // last so that both chains and the per-lane selects around them sit in one basic block.
-template <int NP, bool PARTIAL, bool POSW, int N>
+// GW < 64: `lane` is the lane's index inside its group and every group has its own pixel (rec[n]
+// differs between groups; the group's first lane stores the key word).
+template <int NP, bool PARTIAL, bool POSW, int N, int GW = 64>
 __device__ __forceinline__ void wta_pixels(const Pack<NP> (&Sn)[N], int lane, bool active, int D, int uniq,
                                            uint2 *const (&rec)[N])
 {
@@ -110,7 +122,7 @@ __device__ __forceinline__ void wta_pixels(const Pack<NP> (&Sn)[N], int lane, bo
         if (PARTIAL && !active) kmin = 0xffffffffu;
         key[n] = kmin;
     }
-    wave_min_u32_n<N>(key);  // (minS << 16) | first best d
+    group_min_u32_n<GW, N>(key);  // (minS << 16) | first best d
     const int wgt = 100 - uniq;
     uint32_t far[N], vm[N], vp[N];
     bool has_m[N], has_p[N];
@@ -149,7 +161,7 @@ __device__ __forceinline__ void wta_pixels(const Pack<NP> (&Sn)[N], int lane, bo
         }
         far[n] = min(f & 0xffffu, f >> 16);  // one value per lane: the chain can use v_min_u32_dpp
     }
-    if (POSW) wave_min_u32_n<N>(far);  // D >= 16: disparities outside best-1..best+1 always exist
+    if (POSW) group_min_u32_n<GW, N>(far);  // D >= 16: disparities outside best-1..best+1 always exist
 #pragma unroll
     for (int n = 0; n < N; n++) {
         const int minS = (int)(key[n] >> 16), best = (int)(key[n] & 0xffffu);
@@ -167,7 +179,13 @@ __device__ __forceinline__ void wta_pixels(const Pack<NP> (&Sn)[N], int lane, bo
                 bad |= (__mul24(shi, wgt) < thr) && (abs(best - d0 - 1) > 1);
             }
             if (PARTIAL) bad = bad && active;
-            reject = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+            if constexpr (GW == 64) {
+                reject = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+            } else {  // "any lane of my group"
+                uint32_t t[1] = {bad ? 0u : 1u};
+                group_min_u32_n<GW, 1>(t);
+                reject = t[0] == 0u;
+            }
         }
         // all costs saturated: upstream keeps bestDisp = -1; the pixel ends invalid and never
         // wins a right-view slot (32767 > 32767 is false)

@@ -123,6 +123,64 @@ template <int N> __device__ __forceinline__ void wave_min_u32_n(uint32_t (&x)[N]
     for (int n = 0; n < N; n++) x[n] = __builtin_amdgcn_readlane(x[n], 63);
 }
 
+// ---- lane groups (small D): a wave of 64 lanes holds 64/GW independent pixels of GW lanes each ----
+// Reductions that leave the group's result in EVERY lane of the group (a VGPR value that differs
+// between groups); GW = 64 is the wave-uniform case above.
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <int GW, int N> __device__ __forceinline__ void group_min_pk_n(uint32_t (&x)[N])
+{
+    if constexpr (GW == 64) {
+        wave_min_pk_n<N>(x);
+    } else {
+#define SGM_STEP(CTRL, MASK) \
+    _Pragma("unroll") for (int n = 0; n < N; n++) x[n] = pk_min_s(x[n], dpp_view<CTRL, MASK>(x[n]));
+        SGM_STEP(DPP_QUAD_1032, 0xf)
+        SGM_STEP(DPP_QUAD_2301, 0xf)
+        SGM_STEP(DPP_ROW_HALF_MIRROR, 0xf)  // 8 lanes done
+        if constexpr (GW >= 16) { SGM_STEP(DPP_ROW_MIRROR, 0xf) }
+        if constexpr (GW == 32) {
+            SGM_STEP(DPP_ROW_BCAST15, 0xa)  // lanes 31 / 63 now hold the minimum of rows 0-1 / 2-3
+            const bool lower = lane_id() < 32;
+#pragma unroll
+            for (int n = 0; n < N; n++) {
+                const uint32_t a = __builtin_amdgcn_readlane(x[n], 31), b = __builtin_amdgcn_readlane(x[n], 63);
+                x[n] = lower ? a : b;
+            }
+        }
+#undef SGM_STEP
+    }
+}
+template <int GW, int N> __device__ __forceinline__ void group_min_u32_n(uint32_t (&x)[N])
+{
+    if constexpr (GW == 64) {
+        wave_min_u32_n<N>(x);
+    } else {
+#define SGM_STEP(CTRL, MASK) \
+    _Pragma("unroll") for (int n = 0; n < N; n++) x[n] = min(x[n], dpp_view<CTRL, MASK>(x[n]));
+        SGM_STEP(DPP_QUAD_1032, 0xf)
+        SGM_STEP(DPP_QUAD_2301, 0xf)
+        SGM_STEP(DPP_ROW_HALF_MIRROR, 0xf)
+        if constexpr (GW >= 16) { SGM_STEP(DPP_ROW_MIRROR, 0xf) }
+        if constexpr (GW == 32) {
+            SGM_STEP(DPP_ROW_BCAST15, 0xa)
+            const bool lower = lane_id() < 32;
+#pragma unroll
+            for (int n = 0; n < N; n++) {
+                const uint32_t a = __builtin_amdgcn_readlane(x[n], 31), b = __builtin_amdgcn_readlane(x[n], 63);
+                x[n] = lower ? a : b;
+            }
+        }
+#undef SGM_STEP
+    }
+}
+template <int GW> __device__ __forceinline__ uint32_t group_min_pk(uint32_t x)
+{
+    uint32_t a[1] = {x};
+    group_min_pk_n<GW, 1>(a);
+    return a[0];
+}
+
 // NP packed registers per lane, moved as one vector access
 template <int NP> struct PackVec;
 template <> struct PackVec<1> { typedef uint32_t type; };

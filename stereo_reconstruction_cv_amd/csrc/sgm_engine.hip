@@ -19,6 +19,7 @@
 #include "kernels_post.h"
 #include "kernels_rectify.h"
 #include "kernels_sweep.h"
+#include "kernels_group.h"
 
 using namespace sgm;
 
@@ -203,6 +204,33 @@ static void launch_path(const Geom &g, int rx, int ry, int mode, const int16_t *
 }
 
 // ---- sweep launch dispatch --------------------------------------------------------------------
+// ---- small D: lane-grouped kernels (kernels_group.h) ----
+static int group_width(const Geom &g, int H)
+{
+    if (g.D > 64 || (int64_t)H * g.rowsz * 2 >= (int64_t)0x7fff0000) return 64;
+    return g.D <= 16 ? 8 : (g.D <= 32 ? 16 : 32);
+}
+template <int GW>
+static void launch_rows_g(const Geom &g, int H, int rx, int mode, const int16_t *C, int16_t *S, int keepS, uint2 *wta, hipStream_t st)
+{
+    constexpr int G = 64 / GW;
+    dim3 grid((H + G - 1) / G), block(64);
+    if (mode == PATH_FIRST)
+        hipLaunchKernelGGL((k_rows_g<GW, PATH_FIRST, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
+    else if (mode == PATH_ACCUM)
+        hipLaunchKernelGGL((k_rows_g<GW, PATH_ACCUM, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
+    else if (g.uniq < 100)
+        hipLaunchKernelGGL((k_rows_g<GW, PATH_LAST, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
+    else
+        hipLaunchKernelGGL((k_rows_g<GW, PATH_LAST, false>), grid, block, 0, st, g, rx, C, S, keepS, wta);
+}
+static void launch_rows_grouped(const Geom &g, int H, int GW, int rx, int mode, const int16_t *C, int16_t *S, int keepS, uint2 *wta, hipStream_t st)
+{
+    if (GW == 8) launch_rows_g<8>(g, H, rx, mode, C, S, keepS, wta, st);
+    else if (GW == 16) launch_rows_g<16>(g, H, rx, mode, C, S, keepS, wta, st);
+    else launch_rows_g<32>(g, H, rx, mode, C, S, keepS, wta, st);
+}
+
 template <int NP, bool PARTIAL, int MODE, bool POSW>
 static int launch_sweep_one(const Geom &g, const SweepArgs &a, int nbands, hipStream_t st)
 {
@@ -495,7 +523,9 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             }
             if (g.mode == 0) {
                 if ((rc = stage_begin(e, "path_W_wta"))) return rc;
-                launch_path(g, -1, 0, PATH_LAST, C, S, e->keep_aggr, wta, st);
+                const int GW = (e->debug & 4) ? 64 : group_width(g, H);  // debug 4: no lane groups (A/B)
+                if (GW < 64) launch_rows_grouped(g, H, GW, -1, PATH_LAST, C, S, e->keep_aggr, wta, st);
+                else launch_path(g, -1, 0, PATH_LAST, C, S, e->keep_aggr, wta, st);
                 KCHECK();
                 if ((rc = stage_end(e, 1))) return rc;
             }
