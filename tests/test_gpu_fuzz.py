@@ -1,0 +1,47 @@
+"""Randomised parity sweep (fixed seeds): every constructor argument of cv2.StereoSGBM_create that
+the path honours, odd shapes, both modes, both schedules -- all stage taps bit-exact against the
+oracle.  Cases that leave the int16 no-overflow regime are skipped, not compared."""
+import numpy as np
+import pytest
+
+import parity_util as U
+from oracle import oracle as O
+from stereo_reconstruction_cv_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    D = 16 * int(rng.integers(1, 33)) if seed % 3 else 16 * int(rng.integers(1, 5))   # a third of the cases: D <= 64
+    bs = int(rng.choice([1, 3, 5, 7, 9, 11]))
+    minD = int(rng.integers(-24, 25))
+    mode = int(rng.integers(0, 2))
+    H = int(rng.integers(1, 28))
+    W = D + abs(minD) + int(rng.integers(1, 90))
+    P1 = int(rng.integers(1, 12 * bs * bs + 2))
+    P2 = P1 + int(rng.integers(1, 40 * bs * bs + 2))
+    p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=P1, P2=P2,
+             disp12MaxDiff=int(rng.integers(-1, 4)), preFilterCap=int(rng.integers(1, 64)),
+             uniquenessRatio=int(rng.choice([0, 1, 5, 10, 15, 40, 99, 100, 120])),
+             speckleWindowSize=int(rng.choice([0, 5, 30, 200])), speckleRange=int(rng.integers(1, 5)), mode=mode)
+    return H, W, D, p, int(rng.integers(0, 10 ** 6))
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_parameters_bit_exact(seed):
+    H, W, D, p, img_seed = _case(seed)
+    l, r, _ = synth.make_pair(H, W, max(D, 16), img_seed)
+    if seed % 5 == 0:   # plain noise instead of a matchable pair: WTA ties, rejected pixels, speckles everywhere
+        rng = np.random.default_rng(img_seed)
+        l = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        r = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    want, t = O.sgbm_compute(l, r, taps=True, **p)
+    if not t["headroom_ok"]:
+        pytest.skip("input leaves the int16 no-overflow regime")
+    t["disp"] = want
+    for schedule in (1, 0):
+        h = U.run_hip_with_taps(l, r, p, schedule=schedule, sweep_rows=[0, 1, 2, 4][seed % 4] if schedule else 0)
+        bad = [U.describe_mismatch(k, h[k], t[k]) for k in ("C", "S", "disp_raw", "disp_median", "disp")
+               if k in h and k in t and not np.array_equal(h[k], t[k])]
+        assert not bad, f"schedule {schedule} {p} {H}x{W}\n" + "\n".join(bad)
