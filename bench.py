@@ -80,11 +80,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    # BENCH_REHEARSE=1: functional rehearsal of the N > 1 code path on a box with fewer GPUs than
+    # ranks -- every rank uses cuda:(local_rank % device_count) and the rendezvous runs over gloo
+    # (RCCL refuses two ranks on one GPU).  Its numbers mean nothing; the driver never sets it.
+    rehearse = os.environ.get("BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     H, W, D, bs, mode, ppg, with_xyz, desc = WORKLOADS[args.workload]
     p = sgbm_params(D, bs, mode)
@@ -138,7 +147,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -197,7 +206,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "int16",
-        "data": "synthetic",
+        "data": "synthetic" + (" (BENCH_REHEARSE: ranks share GPUs, numbers meaningless)" if rehearse else ""),
         "config": {"workload": f"{args.workload}: {desc}", "height": H, "width": W, "numDisparities": D,
                    "blockSize": bs, "mode": "MODE_HH" if mode else "MODE_SGBM", "pairs_per_gpu_per_step": ppg,
                    "global_pairs_per_step": ppg * world, "streams_per_gpu": nconc,
