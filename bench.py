@@ -179,7 +179,7 @@ def main():
     k_ms = float(mean_ms[names.index(dom)])
     achieved = alg[dom] / (k_ms * 1e-3) / 1e9
     kname = {"sweep_dn": "k_sweep<NP,*,SWEEP_FIRST>", "sweep_up_wta": "k_sweep<NP,*,SWEEP_LAST>",
-             "path_W_wta": "k_path<NP,*,PATH_LAST>"}.get(dom, "k_path<NP,*,PATH_ACCUM>" if dom.startswith("path_") else dom)
+             "sweep_up": "k_sweep<NP,*,SWEEP_ACCUM>", "path_W_wta": "k_path<NP,*,PATH_LAST>"}.get(dom, "k_path<NP,*,PATH_ACCUM>" if dom.startswith("path_") else dom)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):

@@ -65,6 +65,131 @@ __global__ __launch_bounds__(256) void k_select(Geom g, const uint2 *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Winner-take-all over the finished S volume, one LANE per pixel ("transposed" WTA).
+//
+// Inside the path kernels a pixel's D disparities are spread over the 64 lanes, so the argmin and
+// the uniqueness test are wave reductions: ~110 instructions per pixel of a latency-bound kernel.
+// Read back from HBM the same S vector can be scanned by a single lane with no cross-lane work:
+// a block stages 64 consecutive pixels (64 * D * 2 bytes, one coalesced sweep) into LDS with a
+// padded row stride, then every lane walks its own pixel twice --
+//   pass 1: key = min over d of (S[d] << 16 | d)              -> minS and the FIRST best d
+//   pass 2: far = min of S[d] over |d - best| > 1 (packed)    -> uniqueness (A.6 step 2)
+// ~20 wave instructions per pixel, no dependent chain between pixels; the kernel is bound by
+// reading V once.  Same record format as wta_pixels (kernels_path.h); same arithmetic as the
+// selection loop of oracle/sgbm_oracle.c.
+constexpr int wta_t_stride(int D) { return D * 2 + 8; }  // bytes per staged pixel row (8-byte aligned, breaks the bank stride)
+
+// LG = log2(chunks per row) when D is a power of two (16..512): compile-time trip counts, the next
+// block's loads prefetched into registers during the current block's scan.  LG = -1: any D
+// (multiple of 16), plain staging.
+template <bool POSW, int LG>
+__global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict__ S, uint2 *__restrict__ wta, int64_t npix)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t rows[];
+    const int lane = threadIdx.x, D = LG >= 0 ? (8 << LG) : g.D, W1 = g.W1;
+    const int stride = wta_t_stride(D);
+    const int cpr = D * 2 / 16;  // 16-byte chunks per pixel row; a lane moves cpr chunks per block
+    const int64_t nblocks = (npix + 63) / 64;
+    constexpr int PF = LG < 0 ? 8 : (LG >= 5 ? 32 : (1 << LG));  // chunks per lane held in registers
+    uint4 v[PF];
+    // chunk c = lane + 64 k of the block's contiguous 64 * D * 2 bytes: loads with a clamped index
+    // (no branch between them), committed to the padded LDS rows afterwards
+    auto issue = [&](int64_t blk, int k0) {
+        const int total = (int)min<int64_t>(64, npix - blk * 64) * cpr;
+        const uint4 *src = reinterpret_cast<const uint4 *>(S + blk * 64 * D);
+#pragma unroll
+        for (int u = 0; u < PF; u++) v[u] = src[min(lane + 64 * (k0 + u), total - 1)];
+    };
+    auto commit = [&](int64_t blk, int k0) {
+        const int total = (int)min<int64_t>(64, npix - blk * 64) * cpr;
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int c = lane + 64 * (k0 + u);
+            if (c < total) {
+                const int px = LG >= 0 ? c >> LG : c / cpr, w = c - px * cpr;
+                uint2 *dst = reinterpret_cast<uint2 *>(rows + px * stride + w * 16);
+                dst[0] = make_uint2(v[u].x, v[u].y);
+                dst[1] = make_uint2(v[u].z, v[u].w);
+            }
+        }
+    };
+    int64_t blk = blockIdx.x;
+    if (LG >= 0 && blk < nblocks) issue(blk, 0);
+    for (; blk < nblocks; blk += gridDim.x) {
+    const int64_t p0 = blk * 64;
+    const int np = (int)min<int64_t>(64, npix - p0);
+    __syncthreads();  // (one wave per block: orders the LDS traffic of consecutive blocks)
+    if (LG >= 0) {
+        commit(blk, 0);
+        if (LG == 6) {  // D = 512: the second half of the rows, not prefetched
+            issue(blk, PF);
+            commit(blk, PF);
+        }
+    } else {
+        for (int k0 = 0; k0 < cpr; k0 += PF) {  // cpr need not be a multiple of PF: clamped loads, guarded commits
+            issue(blk, k0);
+            const int total = np * cpr;
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int c = lane + 64 * (k0 + u);
+                if (k0 + u < cpr && c < total) {
+                    const int px = c / cpr, w = c - px * cpr;
+                    uint2 *dst = reinterpret_cast<uint2 *>(rows + px * stride + w * 16);
+                    dst[0] = make_uint2(v[u].x, v[u].y);
+                    dst[1] = make_uint2(v[u].z, v[u].w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (LG >= 0 && blk + gridDim.x < nblocks) issue(blk + gridDim.x, 0);  // next block's loads fly during this scan
+    if (lane < np) {
+    const uint8_t *row = rows + lane * stride;
+    // pass 1
+    uint32_t key = 0xffffffffu;
+#pragma unroll 64  // fully unrolled for D <= 256: constant offsets and disparity indices, many LDS reads in flight
+    for (int d0 = 0; d0 < D; d0 += 4) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(row + d0 * 2);
+        const uint32_t k0 = (v.x << 16) | (uint32_t)d0, k1 = (v.x & 0xffff0000u) | (uint32_t)(d0 + 1);
+        const uint32_t k2 = (v.y << 16) | (uint32_t)(d0 + 2), k3 = (v.y & 0xffff0000u) | (uint32_t)(d0 + 3);
+        key = min(min(key, min(k0, k1)), min(k2, k3));
+    }
+    const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
+    const int wgt = 100 - g.uniq, thr = minS * 100;
+    bool reject;
+    // S[best -+ 1] for the sub-pixel step (clamped: k_select uses them only for 0 < best < D-1)
+    const int dm = max(best - 1, 0), dp = min(best + 1, D - 1);
+    uint16_t *rw = reinterpret_cast<uint16_t *>(rows + lane * stride);
+    const uint32_t nb = (uint32_t)rw[dm] | ((uint32_t)rw[dp] << 16);
+    if (POSW) {
+        // wgt > 0: one comparison against the smallest S outside best-1..best+1.  The row in LDS is
+        // this lane's alone and not needed again: overwrite those three entries with MAX_COST and
+        // take a plain packed minimum of the row.
+        rw[dm] = (uint16_t)SGM_MAX_COST;
+        rw[best] = (uint16_t)SGM_MAX_COST;
+        rw[dp] = (uint16_t)SGM_MAX_COST;
+        uint32_t far = SGM_SENT;
+#pragma unroll 64
+        for (int d0 = 0; d0 < D; d0 += 4) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(row + d0 * 2);
+            far = pk_min_s(far, pk_min_s(v.x, v.y));
+        }
+        reject = (int)min(far & 0xffffu, far >> 16) * wgt < thr;
+    } else {
+        reject = false;
+        for (int d = 0; d < D; d++) {
+            const int sv = *reinterpret_cast<const uint16_t *>(row + d * 2);
+            reject |= (sv * wgt < thr) && (abs(best - d) > 1);
+        }
+    }
+    reject = reject || (minS == SGM_MAX_COST);
+    const int64_t p = p0 + lane;
+    const int y = (int)(p / W1), x = (int)(p - (int64_t)y * W1);
+    wta[(int64_t)y * g.W + g.minX1 + x] = make_uint2(reject ? 0xffffffffu : key, nb);
+    }  // lane < np
+    }  // blocks of this workgroup
+}
+
 __device__ __forceinline__ void cswap(int &a, int &b)
 {
     const int lo = min(a, b), hi = max(a, b);

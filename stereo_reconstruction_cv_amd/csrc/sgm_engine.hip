@@ -502,6 +502,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // debug bit 64+128: fork right after the cost stage (both pre-passes side by side) instead
             // of after the downward pre-pass (upward pre-pass beside the downward sweep)
             const bool fork_early = (e->debug & 128) != 0;
+            const bool fused_wta = (e->debug & 2) != 0;  // debug 2: WTA inside the last path kernel (A/B, cross-check)
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
@@ -514,18 +515,56 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 }
                 if (overlap && pass == 0 && !fork_early && (rc = fork_prepass_up())) return rc;
                 if (overlap && pass == 1) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
-                const bool last = pass == npass - 1 && g.mode == 1;
+                // winner-take-all: fused into the last path kernel (debug 2), or -- default -- a
+                // separate pass over S with one lane per pixel (k_wta_t)
+                const bool last = pass == npass - 1 && g.mode == 1 && fused_wta;
                 SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug};
-                if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : "sweep_up_wta"))) return rc;
+                if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up")))) return rc;
                 if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) return rc;
                 KCHECK();
                 if ((rc = stage_end(e, 1))) return rc;
             }
             if (g.mode == 0) {
-                if ((rc = stage_begin(e, "path_W_wta"))) return rc;
+                if ((rc = stage_begin(e, fused_wta ? "path_W_wta" : "path_W"))) return rc;
                 const int GW = (e->debug & 4) ? 64 : group_width(g, H);  // debug 4: no lane groups (A/B)
-                if (GW < 64) launch_rows_grouped(g, H, GW, -1, PATH_LAST, C, S, e->keep_aggr, wta, st);
-                else launch_path(g, -1, 0, PATH_LAST, C, S, e->keep_aggr, wta, st);
+                const int pm = fused_wta ? PATH_LAST : PATH_ACCUM;
+                if (GW < 64) launch_rows_grouped(g, H, GW, -1, pm, C, S, e->keep_aggr, wta, st);
+                else launch_path(g, -1, 0, pm, C, S, e->keep_aggr, wta, st);
+                KCHECK();
+                if ((rc = stage_end(e, 1))) return rc;
+            }
+            if (!fused_wta) {
+                if ((rc = stage_begin(e, "wta"))) return rc;
+                const int64_t npix = (int64_t)H * g.W1;
+                const size_t lds = (size_t)64 * wta_t_stride(g.D);
+                // persistent blocks: LDS (64 padded rows) allows four waves per CU; each loops over its share
+                dim3 grid((unsigned)std::min<int64_t>((npix + 63) / 64, 4 * 256)), block(64);
+                int lgc = -1;  // log2(D / 8) when D is a power of two
+                for (int q = 1; q <= 6; q++)
+                    if (g.D == (8 << q)) lgc = q;
+#define SGM_WTA(POSW_, LG_)                                                                                            \
+    do {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                           \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_wta_t<POSW_, LG_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                                    \
+        hipLaunchKernelGGL((k_wta_t<POSW_, LG_>), grid, block, lds, st, g, (const int16_t *)S, wta, npix);               \
+    } while (0)
+#define SGM_WTA_LG(POSW_)                       \
+    do {                                        \
+        switch (lgc) {                          \
+        case 1: SGM_WTA(POSW_, 1); break;       \
+        case 2: SGM_WTA(POSW_, 2); break;       \
+        case 3: SGM_WTA(POSW_, 3); break;       \
+        case 4: SGM_WTA(POSW_, 4); break;       \
+        case 5: SGM_WTA(POSW_, 5); break;       \
+        case 6: SGM_WTA(POSW_, 6); break;       \
+        default: SGM_WTA(POSW_, -1); break;     \
+        }                                       \
+    } while (0)
+                if (g.uniq < 100) SGM_WTA_LG(true);
+                else SGM_WTA_LG(false);
+#undef SGM_WTA_LG
+#undef SGM_WTA
                 KCHECK();
                 if ((rc = stage_end(e, 1))) return rc;
             }

@@ -26,14 +26,16 @@ for v in variants:
     e.set_option(_lib.SGM_OPT_SWEEP_ROWS, v // 1000)
     engs[v] = e
 acc = {v: [] for v in variants}
+vnames = {}
 for rnd in range(6):
     for v in variants:
         engs[v].compute_device(dl.data_ptr(), dr.data_ptr(), H, W, W, out.data_ptr())
         st = engs[v].stage_times()
         if rnd > 0:
             acc[v].append([m for _, m, _ in st])
-        names = [n for n, _, _ in st]
+        vnames[v] = [n for n, _, _ in st]   # stage lists differ between variants
 for v in variants:
+    names = vnames[v]
     a = np.median(np.array(acc[v]), axis=0)
     wall = a[names.index("_wall")] if "_wall" in names else a.sum()
     print(f"debug={v:3d} wall {wall:6.2f} ms  " + " ".join(f"{n}={m:.2f}" for n, m in zip(names, a) if m > 0.25 and n != "_wall"), flush=True)
