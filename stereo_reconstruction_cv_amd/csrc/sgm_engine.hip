@@ -502,7 +502,11 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // debug bit 64+128: fork right after the cost stage (both pre-passes side by side) instead
             // of after the downward pre-pass (upward pre-pass beside the downward sweep)
             const bool fork_early = (e->debug & 128) != 0;
-            const bool fused_wta = (e->debug & 2) != 0;  // debug 2: WTA inside the last path kernel (A/B, cross-check)
+            // Winner-take-all: a separate pass over S (k_wta_t) after the second sweep of MODE_HH and
+            // after the lane-grouped in-row path of small D; fused into the in-row path kernel for
+            // MODE_SGBM with D > 64 (that kernel is latency-bound per row, the WTA rides along).
+            // debug 2 forces the fused form everywhere (A/B, cross-check).
+            const bool fused_wta = (e->debug & 2) != 0 || (g.mode == 0 && ((e->debug & 4) || group_width(g, H) == 64));
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;

@@ -269,3 +269,21 @@ def test_fused_sweeps_repeatable(D, W):
             h = U.run_hip_with_taps(l, r, p, schedule=1, sweep_rows=rows)
             assert np.array_equal(h["S"], ref["S"]), (trial, rows)
             assert np.array_equal(h["disp"], ref["disp"]), (trial, rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,W,mode", [(512, 700, 1), (256, 500, 1), (64, 200, 1), (16, 120, 0), (128, 300, 0)])
+def test_both_winner_take_all_forms(D, W, mode):
+    """The WTA runs either inside the last path kernel (k_sweep / k_path / k_rows_g, PATH_LAST) or as
+    its own pass over S (k_wta_t); the engine picks per mode and D, debug bit 2 forces the fused
+    form.  Both must give the oracle's disparities and identical S."""
+    H = 18
+    l, r, _ = synth.make_pair(H, W, D, 5)
+    p = U.params(D, 5, 0, mode, speckleWindowSize=30, speckleRange=2)
+    want, t = O.sgbm_compute(l, r, taps=True, **p)
+    assert t["headroom_ok"]
+    for debug in (0, 2):
+        h = U.run_hip_with_taps(l, r, p, schedule=1, debug=debug)
+        assert np.array_equal(h["S"], t["S"]), debug
+        assert np.array_equal(h["disp_raw"], t["disp_raw"]), debug
+        assert np.array_equal(h["disp"], want), debug
