@@ -185,8 +185,8 @@ def main():
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            if rec.get("workload") == args.workload and rec.get("stage") == dom:
-                traffic = rec.get("traffic_bytes_per_launch")
+            if rec.get("workload") == args.workload:  # per-stage PMC records of the committed profile run
+                traffic = rec.get("stages", {}).get(dom, {}).get("traffic_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
 
