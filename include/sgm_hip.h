@@ -85,7 +85,13 @@ typedef enum {
     SGM_OPT_PROFILE = 1,     /* 1: bracket every stage with HIP events on the engine's stream    */
     SGM_OPT_SCHEDULE = 2,    /* 0: one kernel per path direction; 1 (default): fused 4-direction sweeps */
     SGM_OPT_SWEEP_ROWS = 3,  /* rows per band of the fused sweep; 0 = automatic                  */
-    SGM_OPT_DEBUG = 4        /* timing experiments only: non-zero values make results WRONG      */
+    SGM_OPT_DEBUG = 4        /* A/B switches for measurements, a bit mask.  Results stay correct except
+                              * for bit 64.   2: winner-take-all fused into the last path kernel
+                              * everywhere;  4: no lane groups for D <= 64;  8: narrow vertical box
+                              * sum;  16: boundary pre-pass as three k_path launches;  32: no overlap of
+                              * the upward pre-pass with the downward sweep;  64: the sweep's loader wave
+                              * skips its HBM loads (timing only, results WRONG);  128: fork the upward
+                              * pre-pass right after the cost stage */
 } sgm_option;
 
 #define SGM_MAX_STAGES 32
