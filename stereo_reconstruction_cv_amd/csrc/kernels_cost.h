@@ -124,7 +124,7 @@ template <int NP, int RS_T>
 __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ lrec,
                                              const uint8_t *__restrict__ rplanes,
                                              int16_t *__restrict__ hsum, int XL, int nchunks, int RS,
-                                             int ring_bytes, int lrec_bytes, int seg_len)
+                                             int ring_bytes, int lrec_bytes, int seg_len, int y_base)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *ring = reinterpret_cast<uint32_t *>(smem);
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
 
     const int lane = threadIdx.x;
     const int unit = blockIdx.x;
-    const int y = unit / nchunks, ck = unit - y * nchunks;
+    const int yr = unit / nchunks, ck = unit - yr * nchunks;
+    const int y = y_base + yr;  // the launch covers rows y_base .. y_base + gridDim.x / nchunks - 1
     const int W1 = g.W1, SW2 = g.SW2, W = g.W;
     const int xs = ck * XL, xe = min(xs + XL, W1);
     const int j0 = max(xs - SW2 - 1, 0), j1 = min(xe - 1 + SW2, W1 - 1);
@@ -315,13 +316,13 @@ __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, in
 // by RS).  Instantiated for the common block sizes; other sizes use k_vsum.
 template <int SH2_, int NW /* dwords per thread: 2 or 4 */>
 __global__ __launch_bounds__(256) void k_vsum_ring(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
-                                                   int H, int64_t rowsz, int RB /* multiple of RS */)
+                                                   int H, int64_t rowsz, int RB /* multiple of RS */, int band0)
 {
     constexpr int RS = SH2_ <= 1 ? 4 : (SH2_ <= 3 ? 8 : (SH2_ <= 7 ? 16 : 32));  // pow2 >= 2*SH2+2
     typedef Pack<NW> V;
     const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (2 * NW);  // 2*NW int16 per thread
     if (e >= rowsz) return;
-    const int y0 = blockIdx.y * RB, y1 = min(y0 + RB, H);
+    const int y0 = (band0 + blockIdx.y) * RB, y1 = min(y0 + RB, H);
     V ring[RS];
     V acc;
     acc.fill(0);

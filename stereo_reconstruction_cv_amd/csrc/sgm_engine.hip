@@ -353,16 +353,16 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         if ((rc = stage_end(e, 2))) return rc;
 
         // -- horizontal box sum of the pixel cost
-        if ((rc = stage_begin(e, "cost_hsum"))) return rc;
-        {
-            const int XL = 128;
-            const int nchunks = (g.W1 + XL - 1) / XL;
-            int RS = 1;  // ring of the last blockSize+1 cost vectors, rounded to a power of two
-            while (RS < 2 * g.SW2 + 2) RS <<= 1;
-            const HsumLds l = hsum_lds_layout(g.NP, RS, XL, g.SW2);
-            dim3 grid((unsigned)((int64_t)H * nchunks)), block(64);
-            const uint2 *lrec = (const uint2 *)e->lrec.p;
-            const uint8_t *rpl = (const uint8_t *)e->rplanes.p;
+        // -- horizontal box sum of the pixel cost (rows y0 .. y1-1), vertical box sum -> block cost
+        const int XL = 128;
+        const int nchunks = (g.W1 + XL - 1) / XL;
+        int RS = 1;  // ring of the last blockSize+1 cost vectors, rounded to a power of two
+        while (RS < 2 * g.SW2 + 2) RS <<= 1;
+        const HsumLds l = hsum_lds_layout(g.NP, RS, XL, g.SW2);
+        const uint2 *lrec = (const uint2 *)e->lrec.p;
+        const uint8_t *rpl = (const uint8_t *)e->rplanes.p;
+        auto launch_hsum = [&](int hs_y0, int hs_y1) -> int {
+            dim3 grid((unsigned)((int64_t)(hs_y1 - hs_y0) * nchunks)), block(64);
             // RS_T = RS instantiations carry the unrolled interior fast path (block sizes up to 15)
 #define SGM_HSUM(NP_, RS_)                                                                                          \
     do {                                                                                                            \
@@ -370,7 +370,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             HIP_TRY(hipFuncSetAttribute((const void *)k_hsum<NP_, RS_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         l.total_bytes));                                                            \
         hipLaunchKernelGGL((k_hsum<NP_, RS_>), grid, block, l.total_bytes, st, g, lrec, rpl, HS, XL, nchunks, RS,    \
-                           l.ring_bytes, l.lrec_bytes, l.seg_len);                                                  \
+                           l.ring_bytes, l.lrec_bytes, l.seg_len, hs_y0);                                           \
     } while (0)
 #define SGM_HSUM_NP(NP_)                    \
     do {                                    \
@@ -384,23 +384,20 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             else SGM_HSUM_NP(4);
 #undef SGM_HSUM_NP
 #undef SGM_HSUM
-            KCHECK();
-        }
-        if ((rc = stage_end(e, 1))) return rc;
-
-        // -- vertical box sum -> block cost
-        if ((rc = stage_begin(e, "cost_vsum"))) return rc;
-        {
-            const int RB = 96;  // multiple of every ring size used below
-            const int16_t *hsp = (const int16_t *)HS;
-            int16_t *cp = (int16_t *)e->cost.p;
+            return SGM_OK;
+        };
+        const int RB = 96;  // rows per band of the vertical sum; multiple of every ring size used below
+        const int nvb = (H + RB - 1) / RB;
+        const int16_t *hsp = (const int16_t *)HS;
+        int16_t *cp = (int16_t *)e->cost.p;
+        auto launch_vsum = [&](int band0, int nb) {
             const bool wide = !(e->debug & 8);  // 8 int16 per thread (debug 8: 4, for A/B timing)
             const int per_thread = wide ? 8 : 4;
-            dim3 block(256), gridr((unsigned)((g.rowsz / per_thread + 255) / 256), (H + RB - 1) / RB);
-#define SGM_VSUM(SH2_)                                                                                      \
-    case SH2_:                                                                                              \
-        if (wide) hipLaunchKernelGGL((k_vsum_ring<SH2_, 4>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB); \
-        else hipLaunchKernelGGL((k_vsum_ring<SH2_, 2>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB);      \
+            dim3 block(256), gridr((unsigned)((g.rowsz / per_thread + 255) / 256), nb);
+#define SGM_VSUM(SH2_)                                                                                             \
+    case SH2_:                                                                                                     \
+        if (wide) hipLaunchKernelGGL((k_vsum_ring<SH2_, 4>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, band0); \
+        else hipLaunchKernelGGL((k_vsum_ring<SH2_, 2>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, band0);      \
         break;
             switch (g.SH2) {  // ring variant: each hsum row is read once
                 SGM_VSUM(1)
@@ -409,13 +406,21 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 SGM_VSUM(4)
                 SGM_VSUM(5)
 #undef SGM_VSUM
-            default: {
-                dim3 grid((unsigned)((g.rowsz / 8 + 255) / 256), (H + 63) / 64);
-                hipLaunchKernelGGL(k_vsum, grid, block, 0, st, hsp, cp, H, g.rowsz, g.SH2, 64);
+            default: break;
             }
-            }
-            KCHECK();
+        };
+        if ((rc = stage_begin(e, "cost_hsum"))) return rc;
+        if ((rc = launch_hsum(0, H))) return rc;
+        KCHECK();
+        if ((rc = stage_end(e, 1))) return rc;
+        if ((rc = stage_begin(e, "cost_vsum"))) return rc;
+        if (g.SH2 >= 1 && g.SH2 <= 5) {
+            launch_vsum(0, nvb);
+        } else {
+            dim3 block(256), grid((unsigned)((g.rowsz / 8 + 255) / 256), (H + 63) / 64);
+            hipLaunchKernelGGL(k_vsum, grid, block, 0, st, hsp, cp, H, g.rowsz, g.SH2, 64);
         }
+        KCHECK();
         if ((rc = stage_end(e, 1))) return rc;
 
         if (e->schedule == 0) {
