@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void k_ccl_count(const int16_t *__restrict__ i
     if (x > 0 && linked(v, img[i - 1], newVal, maxDiff)) return;  // not a run start
     const int r = uf_find(label, (int)i);
     atomicAdd(&csz[r], rlen[i]);
+    if (r != (int)i) atomicMin(&label[i], r);  // run start -> root directly (all unions are done): k_ccl_apply needs one hop
 }
 
 __global__ __launch_bounds__(256) void k_ccl_apply(int16_t *__restrict__ img, int *label,
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void k_ccl_apply(int16_t *__restrict__ img, in
     const int64_t i = (int64_t)y * W + x;
     const int l = label[i];
     if (l < 0) return;
-    const int r = uf_find(label, l);  // l is i itself or i's run start
+    const int r = label[l];  // l is i itself or i's run start, which k_ccl_count pointed at the root
     if (csz[r] <= maxSpeckleSize) img[i] = (int16_t)newVal;
 }
 
