@@ -173,7 +173,7 @@ def main():
             alg[n] = 12 * V
         elif n.startswith("path_"):
             alg[n] = 3 * V
-        elif n in ("cost_hsum", "cost_vsum"):
+        elif n in ("cost_hsum", "cost_vsum", "cost_pix", "cost_box"):
             alg[n] = V // 2
     dom = max(alg, key=lambda n: mean_ms[names.index(n)])
     k_ms = float(mean_ms[names.index(dom)])

@@ -288,6 +288,207 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
     for (; j <= j1; j++) column(j);
 }
 
+// ---- byte pipeline of the block cost (default for window radii 1..5) ----------------------------
+// The per-pixel Birchfield-Tomasi cost is at most 2*ftzero + 63 <= 255: stored as one BYTE per
+// (x, d) it is half the volume of the int16 horizontal sums that k_hsum hands to k_vsum, and the
+// box filter becomes one kernel that reads it back (k_box_u8).  HBM traffic of the cost stage:
+// 0.5 V written + ~0.55 V read + V written, against 3.1 V of k_hsum + k_vsum_ring.
+
+// pix(x, y, d) = BT(gradient channel) + (BT(raw channel) >> 2), one wave per (row, chunk of XL
+// columns), lanes span the disparities, sliding right-feature windows as in k_hsum.
+template <int NP>
+__global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rplanes,
+                                            uint8_t *__restrict__ pix, int XL, int nchunks, int lrec_bytes, int seg_len)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint2 *lds_lrec = reinterpret_cast<uint2 *>(smem);
+    uint8_t *seg = smem + lrec_bytes;
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int y = unit / nchunks, ck = unit - y * nchunks;
+    const int W1 = g.W1, W = g.W;
+    const int j0 = ck * XL, j1 = min(j0 + XL, W1) - 1;
+    const int nj = j1 - j0 + 1;
+    const bool active = 2 * NP * lane < g.D;
+    for (int k = lane; k < nj; k += 64) lds_lrec[k] = lrec[(int64_t)y * W + (j0 + k + g.minX1)];
+    {
+        const int base_j1 = W - 1 - (j1 + g.minX1) + g.minD;  // mirrored position of (column j1, disparity index 0)
+        const int len = (j1 - j0) + 128 * NP;
+        const int64_t psz = (int64_t)g.H * W;
+        for (int s = lane; s < len; s += 64) {
+            const int pos = base_j1 + s;
+            const bool ok = pos >= 0 && pos < W;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                seg[c * seg_len + s] = ok ? rplanes[c * psz + (int64_t)y * W + pos] : (uint8_t)0;
+        }
+    }
+    __syncthreads();
+    uint32_t w[6][NP];
+    {
+        const int off = (j1 - j0) + 2 * NP * lane;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                w[c][i] = (uint32_t)seg[c * seg_len + off + 2 * i] | ((uint32_t)seg[c * seg_len + off + 2 * i + 1] << 16);
+    }
+    // this row of the output; lanes past D store nowhere (offset beyond the descriptor)
+    const int row_bytes = W1 * g.D;
+    const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(pix + (int64_t)y * row_bytes), 0, row_bytes, 0x00020000);
+    const int voff = active ? 2 * NP * lane : row_bytes;
+    int tap[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) tap[c] = c * seg_len + 2 * NP * lane + (j1 - j0);
+    int recp = 0;
+    asm volatile("" : "+v"(recp));  // keep the (wave-uniform) record in VGPRs: v_perm splats, no scalar unpack
+    int so = j0 * g.D;
+    for (int j = j0; j <= j1; j++) {
+        if (j > j0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const uint32_t nw = seg[tap[c] - (j - j0)];
+#pragma unroll
+                for (int i = NP - 1; i >= 1; i--) w[c][i] = __builtin_amdgcn_alignbit(w[c][i], w[c][i - 1], 16);
+                w[c][0] = (w[c][0] << 16) | nw;
+            }
+        }
+        const uint2 rec = lds_lrec[recp + (j - j0)];
+        const uint32_t U = splat_byte<0>(rec.x), U0 = splat_byte<1>(rec.x), U1 = splat_byte<2>(rec.x);
+        const uint32_t R = splat_byte<0>(rec.y), R0 = splat_byte<1>(rec.y), R1 = splat_byte<2>(rec.y);
+        uint32_t pv[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const uint32_t a = bt_pair(U, U0, U1, w[0][i], w[1][i], w[2][i]);
+            const uint32_t b = bt_pair(R, R0, R1, w[3][i], w[4][i], w[5][i]);
+            pv[i] = pk_add(a, pk_shr_u(b, 2));
+        }
+        // low byte of every int16 half: 2*NP bytes per lane, ascending d
+        if constexpr (NP == 1) {
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)__builtin_amdgcn_perm(0u, pv[0], 0x0c0c0200u), orow, voff, so, 0);
+        } else if constexpr (NP == 2) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(pv[1], pv[0], 0x06040200u), orow, voff, so, 0);
+        } else {
+            v2u32 o;
+            o.x = __builtin_amdgcn_perm(pv[1], pv[0], 0x06040200u);
+            o.y = __builtin_amdgcn_perm(pv[3], pv[2], 0x06040200u);
+            __builtin_amdgcn_raw_buffer_store_b64(o, orow, voff, so, 0);
+        }
+        so += g.D;
+    }
+}
+
+// C(x, y, d) = sum over the (2R+1)^2 window of pix, window clamped at the edges of the valid-column
+// domain and of the image (A.4).  One wave per XC = 4 adjacent columns, lanes span the disparities,
+// the wave walks down a band of rows.  Per row it loads the 2R+XC neighbouring columns' bytes
+// (adjacent in memory), widens them once, forms hs of its first column by 2R additions and of the
+// next three by hs(x+1) = hs(x) + col(x+R+1) - col(x-R) (true for clamped column indices as well);
+// the vertical running sums keep the last 2R+2 hs vectors of each column in statically indexed
+// register rings.  2.5 bytes read per output byte pair instead of 7: the first version (one column
+// per wave) was bound by L2 traffic.
+template <int R, int NP>
+__global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restrict__ pix, int16_t *__restrict__ C, int RB)
+{
+    constexpr int RS = R <= 1 ? 4 : (R <= 3 ? 8 : 16);  // pow2 >= 2R+2
+    constexpr int XC = 4, NT = 2 * R + XC;
+    constexpr int NQ = (NP + 1) / 2;  // dwords of bytes per lane and column
+    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * XC;
+    const int W1 = g.W1, D = g.D, H = g.H;
+    if (x0 >= W1) return;
+    const bool active = 2 * NP * lane < D;
+    const int y0 = blockIdx.y * RB, y1 = min(y0 + RB, H);
+    const int row_bytes = W1 * D;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)pix, 0, (int)min<int64_t>((int64_t)H * row_bytes, 0x7ffffff0), 0x00020000);
+    int coff[NT];  // byte offset of the clamped neighbour columns inside a row, this lane's disparities
+#pragma unroll
+    for (int t = 0; t < NT; t++) coff[t] = min(max(x0 + t - R, 0), W1 - 1) * D + 2 * NP * lane;
+    // hs(x0 + c, y) for c = 0..XC-1: NP packed pairs each
+    auto hsum_row = [&](int y, uint32_t (&hs)[XC][NP]) {
+        const int so = min(max(y, 0), H - 1) * row_bytes;  // (< 2 GiB: larger pix volumes use the int16 pipeline)
+        uint32_t v[NT][NQ];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if constexpr (NP == 1) v[t][0] = __builtin_amdgcn_raw_buffer_load_b16(prs, coff[t], so, 0);
+            else if constexpr (NP == 2) v[t][0] = __builtin_amdgcn_raw_buffer_load_b32(prs, coff[t], so, 0);
+            else {
+                const v2u32 q = __builtin_amdgcn_raw_buffer_load_b64(prs, coff[t], so, 0);
+                v[t][0] = q.x;
+                v[t][1] = q.y;
+            }
+        }
+        uint32_t u[NT][NP];  // widened: byte 2i, 2i+1 -> packed pair i
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                u[t][i] = (i & 1) ? __builtin_amdgcn_perm(0u, v[t][i / 2], 0x0c030c02u) : __builtin_amdgcn_perm(0u, v[t][i / 2], 0x0c010c00u);
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            uint32_t h = u[0][i];
+#pragma unroll
+            for (int t = 1; t <= 2 * R; t++) h = pk_add(h, u[t][i]);
+            hs[0][i] = h;
+#pragma unroll
+            for (int c = 1; c < XC; c++) {
+                h = pk_sub(pk_add(h, u[2 * R + c][i]), u[c - 1][i]);
+                hs[c][i] = h;
+            }
+        }
+    };
+    uint32_t ring[RS][XC][NP], acc[XC][NP], hs[XC][NP];
+#pragma unroll
+    for (int c = 0; c < XC; c++)
+#pragma unroll
+        for (int i = 0; i < NP; i++) acc[c][i] = 0;
+    // window of row y0: rows y0-R .. y0+R (y0 % RS == 0: slot(y0 + j) = j & (RS-1) is static)
+#pragma unroll
+    for (int j = -R; j <= R; j++) {
+        hsum_row(y0 + j, hs);
+#pragma unroll
+        for (int c = 0; c < XC; c++)
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                ring[j & (RS - 1)][c][i] = hs[c][i];
+                acc[c][i] = pk_add(acc[c][i], hs[c][i]);
+            }
+    }
+    const int64_t rowsz = (int64_t)W1 * D;
+    int16_t *out = C + (int64_t)x0 * D + 2 * NP * lane;
+    auto put = [&](int y) {
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < XC; c++)
+                if (x0 + c < W1) {
+                    Pack<NP> o;
+#pragma unroll
+                    for (int i = 0; i < NP; i++) o.r[i] = acc[c][i];
+                    o.store(out + (int64_t)y * rowsz + c * D);
+                }
+        }
+    };
+    put(y0);
+    for (int yb = y0; yb < y1; yb += RS) {
+#pragma unroll
+        for (int u = 0; u < RS; u++) {
+            const int y = yb + u;
+            if (y > y0 && y < y1) {
+                hsum_row(y + R, hs);
+#pragma unroll
+                for (int c = 0; c < XC; c++)
+#pragma unroll
+                    for (int i = 0; i < NP; i++) {
+                        acc[c][i] = pk_sub(pk_add(acc[c][i], hs[c][i]), ring[(u - R - 1) & (RS - 1)][c][i]);
+                        ring[(u + R) & (RS - 1)][c][i] = hs[c][i];
+                    }
+                put(y);
+            }
+        }
+    }
+}
+
 // C(y) = sum_{j=-SH2..SH2} hsum(clamp(y+j, 0, H-1)), running along y inside a band of rows.
 __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
                                               int H, int64_t rowsz, int SH2, int RB)

@@ -409,6 +409,50 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             default: break;
             }
         };
+        // Byte pipeline (default): k_pix writes the per-pixel cost as uint8, k_box_u8 does the whole box
+        // filter from it.  Needs a window radius 1..5 (instantiations), a cost that fits a byte, and a
+        // pix volume below the 2 GiB a buffer descriptor spans here.  debug 256: the int16 pipeline.
+        const bool byte_cost = !(e->debug & 256) && g.SW2 >= 1 && g.SW2 <= 5 && 2 * g.ftzero + 63 <= 255 &&
+                               (int64_t)H * g.rowsz < (int64_t)0x7ff00000;
+        if (byte_cost) {
+            if ((rc = stage_begin(e, "cost_pix"))) return rc;
+            {
+                const int nj = XL + 2;
+                const int lrec_b = ((nj * 8) + 15) & ~15;
+                const int seg_l = (nj + 128 * g.NP + 15) & ~15;
+                const size_t lds = (size_t)lrec_b + 6 * (size_t)seg_l;
+                dim3 grid((unsigned)((int64_t)H * nchunks)), block(64);
+                uint8_t *px = (uint8_t *)HS;
+                if (g.NP == 1) hipLaunchKernelGGL(k_pix<1>, grid, block, lds, st, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l);
+                else if (g.NP == 2) hipLaunchKernelGGL(k_pix<2>, grid, block, lds, st, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l);
+                else hipLaunchKernelGGL(k_pix<4>, grid, block, lds, st, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l);
+            }
+            KCHECK();
+            if ((rc = stage_end(e, 1))) return rc;
+            if ((rc = stage_begin(e, "cost_box"))) return rc;
+            {
+                dim3 grid((g.W1 + 15) / 16, nvb), block(256);  // 4 waves x 4 columns per workgroup
+                const uint8_t *px = (const uint8_t *)HS;
+                int16_t *cp2 = (int16_t *)e->cost.p;
+#define SGM_BOX(R_)                                                                               \
+    case R_:                                                                                      \
+        if (g.NP == 1) hipLaunchKernelGGL((k_box_u8<R_, 1>), grid, block, 0, st, g, px, cp2, RB);  \
+        else if (g.NP == 2) hipLaunchKernelGGL((k_box_u8<R_, 2>), grid, block, 0, st, g, px, cp2, RB); \
+        else hipLaunchKernelGGL((k_box_u8<R_, 4>), grid, block, 0, st, g, px, cp2, RB);            \
+        break;
+                switch (g.SW2) {
+                    SGM_BOX(1)
+                    SGM_BOX(2)
+                    SGM_BOX(3)
+                    SGM_BOX(4)
+                    SGM_BOX(5)
+                default: break;
+                }
+#undef SGM_BOX
+            }
+            KCHECK();
+            if ((rc = stage_end(e, 1))) return rc;
+        } else {
         if ((rc = stage_begin(e, "cost_hsum"))) return rc;
         if ((rc = launch_hsum(0, H))) return rc;
         KCHECK();
@@ -422,6 +466,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         }
         KCHECK();
         if ((rc = stage_end(e, 1))) return rc;
+        }  // int16 pipeline
 
         if (e->schedule == 0) {
             // -- v1 schedule: one kernel per direction, vertical-ish first, horizontal last (WTA)
