@@ -411,8 +411,9 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         };
         // Byte pipeline (default): k_pix writes the per-pixel cost as uint8, k_box_u8 does the whole box
         // filter from it.  Needs a window radius 1..5 (instantiations), a cost that fits a byte, and a
-        // pix volume below the 2 GiB a buffer descriptor spans here.  debug 256: the int16 pipeline.
-        const bool byte_cost = !(e->debug & 256) && g.SW2 >= 1 && g.SW2 <= 5 && 2 * g.ftzero + 63 <= 255 &&
+        // pix volume below the 2 GiB a buffer descriptor spans here; for D <= 64 (mostly idle lanes in
+        // both kernels) the int16 pipeline is faster.  debug 256: the int16 pipeline always.
+        const bool byte_cost = !(e->debug & 256) && g.D > 64 && g.SW2 >= 1 && g.SW2 <= 5 && 2 * g.ftzero + 63 <= 255 &&
                                (int64_t)H * g.rowsz < (int64_t)0x7ff00000;
         if (byte_cost) {
             if ((rc = stage_begin(e, "cost_pix"))) return rc;
