@@ -78,3 +78,23 @@ def test_median_network_is_a_median():
             lo, hi = min(v[a], v[b]), max(v[a], v[b])
             v[a], v[b] = lo, hi
         assert v[4] == want
+
+
+def test_no_wide_buffer_stores_in_the_kernel_isa():
+    """Round-1 finding: a buffer_store_dwordx4 with a scalar offset could pick up
+    later contents of its data registers.  The engine never emits one (buf_store<4> issues two
+    64-bit stores); checked on the generated ISA when it is there and current
+    (`make -C stereo_reconstruction_cv_amd/csrc sgm_engine.s`)."""
+    import glob
+    import re
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "stereo_reconstruction_cv_amd", "csrc")
+    isa = os.path.join(csrc, "sgm_engine.s")
+    srcs = glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "sgm_engine.hip")]
+    if not os.path.exists(isa) or os.path.getmtime(isa) < max(os.path.getmtime(f) for f in srcs):
+        pytest.skip("sgm_engine.s absent or older than the sources")
+    text = open(isa).read()
+    assert not re.search(r"buffer_store_dwordx[34]", text)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_masked_writes.py"), isa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
