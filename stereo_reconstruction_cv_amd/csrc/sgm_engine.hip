@@ -83,6 +83,7 @@ struct sgm_engine {
     int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps
     int sweep_rows = 0;  // rows per band of the sweep (0 = automatic)
     int debug = 0;       // timing experiments (SweepArgs::dbg)
+    sgm_engine *peer = nullptr;  // second engine (own stream and buffers) for two pairs in flight in sgm_compute_batch
 
     // shape of the last compute
     int H = 0, W = 0;
@@ -762,6 +763,7 @@ void sgm_destroy(sgm_engine *e)
         (void)hipStreamDestroy(e->aux);
     }
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    if (e->peer) sgm_destroy(e->peer);
     delete e;
 }
 
@@ -979,6 +981,10 @@ int sgm_compute(sgm_engine *e, const uint8_t *left, const uint8_t *right, int H,
     return SGM_OK;
 }
 
+// N independent pairs from / to host memory.  Two pairs are in flight: pair i runs on engine i % 2
+// (the engine itself and a peer with its own stream and device buffers, created on first use), so
+// the host-side copies of one pair overlap the kernels of the other and the second pair fills the
+// SIMD slots a single frame leaves idle.
 int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t *rights, int H, int W,
                       int16_t *disps_out, float *xyz_out, const double *Q16)
 {
@@ -988,19 +994,42 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
     HIP_TRY(hipSetDevice(e->device));
     const size_t npx = (size_t)H * W;
     int rc;
-    if ((rc = e->in_left.ensure(npx)) || (rc = e->in_right.ensure(npx)) || (rc = e->disp_out.ensure(npx * 2))) return rc;
-    if (xyz_out && ((rc = e->f32.ensure(npx * 4)) || (rc = e->xyz.ensure(npx * 12)))) return rc;
-    for (int i = 0; i < N; i++) {
-        HIP_TRY(hipMemcpyAsync(e->in_left.p, lefts + (size_t)i * npx, npx, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->in_right.p, rights + (size_t)i * npx, npx, hipMemcpyHostToDevice, e->stream));
-        rc = sgm_pipeline_device(e, e->in_left.p, e->in_right.p, H, W, W, Q16, e->disp_out.p, xyz_out ? e->f32.p : nullptr,
-                                 xyz_out ? e->xyz.p : nullptr);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(disps_out + (size_t)i * npx, e->disp_out.p, npx * 2, hipMemcpyDeviceToHost, e->stream));
-        if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out + (size_t)i * npx * 3, e->xyz.p, npx * 12, hipMemcpyDeviceToHost, e->stream));
-        // pageable host memory: the copies above are synchronous with respect to the stream order
+    if (N > 1 && !e->peer) {
+        if ((rc = sgm_create(&e->params, e->device, nullptr, &e->peer))) return rc;
     }
+    sgm_engine *eng[2] = {e, (N > 1) ? e->peer : e};
+    for (int k = 0; k < (N > 1 ? 2 : 1); k++) {
+        sgm_engine *q = eng[k];
+        q->keep_aggr = 0;
+        q->profile = 0;
+        q->schedule = e->schedule;
+        q->sweep_rows = e->sweep_rows;
+        q->debug = e->debug;
+        if ((rc = q->in_left.ensure(npx)) || (rc = q->in_right.ensure(npx)) || (rc = q->disp_out.ensure(npx * 2))) return rc;
+        if (xyz_out && ((rc = q->f32.ensure(npx * 4)) || (rc = q->xyz.ensure(npx * 12)))) return rc;
+    }
+    // results of pair i are fetched right before its engine is reused for pair i + 2 (pageable host
+    // memory: each copy blocks the host until the engine's stream reaches it -- the other engine
+    // keeps the GPU busy meanwhile)
+    auto fetch = [&](int i) -> int {
+        sgm_engine *q = eng[i & 1];
+        HIP_TRY(hipMemcpyAsync(disps_out + (size_t)i * npx, q->disp_out.p, npx * 2, hipMemcpyDeviceToHost, q->stream));
+        if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out + (size_t)i * npx * 3, q->xyz.p, npx * 12, hipMemcpyDeviceToHost, q->stream));
+        return SGM_OK;
+    };
+    for (int i = 0; i < N; i++) {
+        sgm_engine *q = eng[i & 1];
+        if (i >= 2 && (rc = fetch(i - 2))) return rc;
+        HIP_TRY(hipMemcpyAsync(q->in_left.p, lefts + (size_t)i * npx, npx, hipMemcpyHostToDevice, q->stream));
+        HIP_TRY(hipMemcpyAsync(q->in_right.p, rights + (size_t)i * npx, npx, hipMemcpyHostToDevice, q->stream));
+        rc = sgm_pipeline_device(q, q->in_left.p, q->in_right.p, H, W, W, Q16, q->disp_out.p, xyz_out ? q->f32.p : nullptr,
+                                 xyz_out ? q->xyz.p : nullptr);
+        if (rc) return rc;
+    }
+    for (int i = std::max(0, N - 2); i < N; i++)
+        if ((rc = fetch(i))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (N > 1) HIP_TRY(hipStreamSynchronize(e->peer->stream));
     return SGM_OK;
 }
 

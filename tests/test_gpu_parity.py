@@ -156,12 +156,14 @@ def test_notebook_functions_end_to_end():
 def test_batch_entry_matches_single():
     import stereo_reconstruction_cv_amd as cv
     p = U.params(32, 5)
-    pairs = [synth.make_pair(40, 160, 32, 40 + i)[:2] for i in range(3)]
-    L = np.stack([a for a, _ in pairs]); R = np.stack([b for _, b in pairs])
+    pairs = [synth.make_pair(40, 160, 32, 40 + i)[:2] for i in range(5)]   # odd count: both engines of the
+    L = np.stack([a for a, _ in pairs]); R = np.stack([b for _, b in pairs])   # two-in-flight batch path end differently
     Q = synth.default_Q(160)
     eng = cv.get_engine(p)
     disps, xyz = eng.compute_batch_host(L, R, Q)
-    for i in range(3):
+    one = eng.compute_batch_host(L[:1], R[:1], None)                         # N = 1: no peer engine involved
+    assert np.array_equal(one[0], disps[0])
+    for i in range(5):
         want = O.sgbm_compute(L[i], R[i], **p)
         assert np.array_equal(disps[i], want)
         w = O.reproject(O.disp_to_float(want), Q)
