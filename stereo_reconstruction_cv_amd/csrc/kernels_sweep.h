@@ -2,8 +2,9 @@
 //
 // Replaces one whole pass of upstream computeDisparitySGBM (/root/reference/main.ipynb:668;
 // SURVEY.md A.5): for every pixel the path from the previous pixel of the same row and the
-// three paths from the previously processed row, S = sat(sum), and in the last pass the
-// winner-take-all scan.  Same arithmetic as k_path (path_elem / wta_pixel), different
+// three paths from the previously processed row, S = sat(sum), and -- SWEEP_LAST only; the
+// engine's default runs the winner-take-all as its own pass over S (k_wta_t) after a SWEEP_ACCUM --
+// the winner-take-all scan.  Same arithmetic as k_path (path_elem / wta_pixels), different
 // schedule: traffic per pass is "read C once, write S once" instead of 2-3 volumes per direction.
 //
 // Schedule.  The image is cut into bands of R rows (in sweep order).  One workgroup owns one
@@ -11,8 +12,8 @@
 // recurrence in lockstep, wave r two steps behind wave r-1, one workgroup barrier per step (a
 // step is two pixels for D <= 256): the (normalised) state a row needs from the row above -- three L vectors per pixel --
 // travels through a small LDS ring per wave and never touches HBM.  Bands do not wait for each
-// other: the state of the row above a band comes from the PATH_BOUNDARY pre-pass of k_path
-// (three read-only line scans that store L only at band boundaries); the loader wave prefetches
+// other: the state of the row above a band comes from the boundary pre-pass (k_prepass3: three
+// read-only line scans that store L only at band boundaries); the loader wave prefetches
 // it from HBM into registers and feeds an LDS ring two steps ahead of wave 0.
 //
 // Everything is expressed in the sweep's own pixel order k (x = k or W1-1-k): role A = path
