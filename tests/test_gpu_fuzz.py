@@ -28,7 +28,10 @@ def _case(seed):
     return H, W, D, p, int(rng.integers(0, 10 ** 6))
 
 
-@pytest.mark.parametrize("seed", range(48))
+import os
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SGM_FUZZ_CASES", "48"))))
 def test_random_parameters_bit_exact(seed):
     H, W, D, p, img_seed = _case(seed)
     l, r, _ = synth.make_pair(H, W, max(D, 16), img_seed)
