@@ -290,3 +290,16 @@ def test_both_winner_take_all_forms(D, W, mode):
         assert np.array_equal(h["S"], t["S"]), debug
         assert np.array_equal(h["disp_raw"], t["disp_raw"]), debug
         assert np.array_equal(h["disp"], want), debug
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,D,bs,mode", [(203, 640, 64, 5, 0), (197, 700, 256, 7, 1), (181, 900, 512, 3, 1), (211, 560, 160, 9, 0)])
+def test_medium_frames_every_stage(H, W, D, bs, mode):
+    """Frames tall enough for many bands per sweep (automatic band height), odd heights, every
+    lane packing: all stage taps against the oracle."""
+    l, r, _ = synth.make_pair(H, W, D, 77)
+    p = U.params(D, bs, 0, mode, speckleWindowSize=60, speckleRange=2)
+    rep, t, h = U.compare_stages(l, r, p)
+    assert t["headroom_ok"]
+    bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
+    assert not bad, "\n".join(bad)
