@@ -41,7 +41,7 @@ struct SweepArgs {
 constexpr int SWEEP_MAX_ROWS = 9;  // compute waves per workgroup (640 threads -> 168 VGPRs per lane)
 // pixels a wave advances per lockstep step (one barrier per step): two give the scheduler two
 // independent dependency chains per wave and halve the barrier / LDS round trips per pixel
-__host__ __device__ constexpr int sweep_pps(int NP) { return NP == 4 ? 1 : 2; }
+__host__ __device__ constexpr int sweep_pps(int NP) { return NP == 4 ? 1 : (NP == 1 ? 4 : 2); }
 // pixels of hand-off state kept per producer: consumers run 2 steps behind their producer
 __host__ __device__ constexpr int sweep_ring(int NP) { return 4 * sweep_pps(NP); }
 
