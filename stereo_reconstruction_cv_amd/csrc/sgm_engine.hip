@@ -501,7 +501,12 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             if ((rc = stage_end(e, 1))) return rc;
         } else {
             // -- fused schedule: per pass a read-only boundary pre-pass (3 line scans) + one sweep
-            const int R = sweep_rows_for(g, e->sweep_rows);
+            // D <= 32: rows without hand-off (k_rows4_g): band height 1, the pre-pass stores every row's
+            // state; needs the 3-volume state buffer below the 4 GiB a 32-bit buffer offset reaches.
+            // (At D = 64 the fused sweep is still ahead: 720p 0.35 against 0.39 ms, and 3 V of state.)
+            const int GWs = (e->debug & 4) ? 64 : group_width(g, H);
+            const bool rows4 = GWs <= 16 && e->sweep_rows <= 0 && (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
+            const int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows);
             const int nbands = (H + R - 1) / R;
             const int npass = g.mode == 1 ? 2 : 1;
             const size_t bnd_bytes = (size_t)nbands * g.W1 * 3 * g.D * 2;
@@ -512,6 +517,12 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // roles of the pre-pass: 0 = predecessor one step earlier in the sweep's x order
             // (x - xdir), 1 = same column, 2 = one step later
             auto launch_prepass = [&](int xdir, int ydir, int16_t *bl, hipStream_t on) {
+                if (rows4 && !(e->debug & 16)) {  // lane-grouped lines, state stored after every row
+                    dim3 grid((g.W1 + 64 / GWs - 1) / (64 / GWs)), block(64);
+                    if (GWs == 8) hipLaunchKernelGGL(k_prepass3_g<8>, grid, block, 0, on, g, xdir, ydir, C, bl);
+                    else hipLaunchKernelGGL(k_prepass3_g<16>, grid, block, 0, on, g, xdir, ydir, C, bl);
+                    return;
+                }
                 if (!(e->debug & 16) && (int64_t)g.rowsz * H < (1ll << 31)) {
                     // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant
                     const bool partial = g.D != 128 * g.NP;
@@ -558,7 +569,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // after the lane-grouped in-row path of small D; fused into the in-row path kernel for
             // MODE_SGBM with D > 64 (that kernel is latency-bound per row, the WTA rides along).
             // debug 2 forces the fused form everywhere (A/B, cross-check).
-            const bool fused_wta = (e->debug & 2) != 0 || (g.mode == 0 && ((e->debug & 4) || group_width(g, H) == 64));
+            const bool fused_wta = ((e->debug & 2) != 0 && !rows4) || (g.mode == 0 && ((e->debug & 4) || group_width(g, H) == 64));
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
@@ -573,10 +584,24 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 if (overlap && pass == 1) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
                 // winner-take-all: fused into the last path kernel (debug 2), or -- default -- a
                 // separate pass over S with one lane per pixel (k_wta_t)
-                const bool last = pass == npass - 1 && g.mode == 1 && fused_wta;
+                const bool last = pass == npass - 1 && g.mode == 1 && fused_wta && !rows4;
                 SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug};
                 if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up")))) return rc;
-                if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) return rc;
+                if (rows4) {
+                    dim3 grid((H + 64 / GWs - 1) / (64 / GWs)), block(64);
+                    const int16_t *bq = (const int16_t *)bl;
+#define SGM_ROWS4(GW_)                                                                                          \
+    do {                                                                                                        \
+        if (pass == 0) hipLaunchKernelGGL((k_rows4_g<GW_, PATH_FIRST>), grid, block, 0, st, g, xdir, ydir, C, S, bq); \
+        else hipLaunchKernelGGL((k_rows4_g<GW_, PATH_ACCUM>), grid, block, 0, st, g, xdir, ydir, C, S, bq);     \
+    } while (0)
+                    if (GWs == 8) SGM_ROWS4(8);
+                    else if (GWs == 16) SGM_ROWS4(16);
+                    else SGM_ROWS4(32);
+#undef SGM_ROWS4
+                } else if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) {
+                    return rc;
+                }
                 KCHECK();
                 if ((rc = stage_end(e, 1))) return rc;
             }
