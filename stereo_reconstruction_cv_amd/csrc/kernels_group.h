@@ -22,22 +22,31 @@ constexpr int SGM_OOB = 0x7ffffff0;  // per-lane offset past every volume: loads
 
 // Horizontal direction (the in-row path of a pass that is not fused into a sweep: MODE_SGBM's
 // fifth path with the winner-take-all), G = 64/GW rows per wave.  MODE as in k_path.
-template <int GW, int MODE, bool POSW>
+// GW = 64 (one row per wave, NP = 1, 2 or 4 registers per lane, PARTIAL as in k_path) is the same
+// loop for large D: one buffer resource per row built once, a constant per-lane offset, a scalar
+// pixel offset (k_path's general line cursor spends more scalar than vector instructions per pixel).
+template <int GW, int NP, bool PARTIAL, int MODE, bool POSW>
 __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__restrict__ C, int16_t *__restrict__ S,
                                                int keepS, uint2 *__restrict__ wta)
 {
-    constexpr int G = 64 / GW, NP = 1, PB = 8;
+    constexpr int G = 64 / GW, PB = 8;
+    static_assert(GW == 64 || (NP == 1 && PARTIAL), "lane groups hold D <= 64: one packed register per lane");
     const int lane = threadIdx.x, gi = lane / GW, li = lane % GW;
     const int W1 = g.W1, D = g.D, H = g.H;
     const int y = blockIdx.x * G + gi;
-    const bool active = 2 * li < D && y < H;
+    const bool active = GW == 64 ? (!PARTIAL || 2 * NP * li < D) : (2 * NP * li < D && y < H);
     GroupEdge ge;
     ge.first = li == 0;
     ge.last = li == GW - 1;
-    const int64_t vol = (int64_t)H * W1 * D * 2;
-    const __amdgpu_buffer_rsrc_t Cv = vol_rsrc(C, vol), Sv = vol_rsrc(S, vol);
-    const __amdgpu_buffer_rsrc_t Sst = vol_rsrc(S, (MODE != PATH_LAST || keepS) ? vol : 0);
-    const int voff = active ? y * (W1 * D * 2) + li * 4 : SGM_OOB;
+    const int row_bytes = W1 * D * 2;
+    // GW < 64: the whole volume behind one descriptor, the row in the per-lane offset (volumes of
+    // D <= 64 stay below 2 GiB); GW = 64: this wave's row behind the descriptor
+    const int64_t span = GW == 64 ? (int64_t)row_bytes : (int64_t)H * row_bytes;
+    const int64_t rowoff = GW == 64 ? (int64_t)y * row_bytes : 0;
+    const __amdgpu_buffer_rsrc_t Cv = vol_rsrc((const char *)C + rowoff, span), Sv = vol_rsrc((const char *)S + rowoff, span);
+    const __amdgpu_buffer_rsrc_t Sst = Sv;
+    const bool stores_S = MODE != PATH_LAST || keepS;
+    const int voff = active ? (GW == 64 ? 0 : y * row_bytes) + li * NP * 4 : SGM_OOB;
     const int pxb = D * 2;
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     const uint32_t init = active ? 0u : SGM_SENT;
@@ -63,13 +72,14 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
     auto pixel = [&](const Pack<NP> &cv, const Pack<NP> &sv, int k) {
         Pack<NP> Ln, Lnorm;
         uint32_t rmin;
-        path_elem<NP, true, GW>(cv, L, P1s, P2s, active, Ln, rmin, sr, ge);
+        path_elem<NP, PARTIAL, GW>(cv, L, P1s, P2s, active, Ln, rmin, sr, ge);
         const uint32_t m = group_min_pk<GW>(rmin);
-        path_normalise<NP, true>(Ln, min(m & 0xffffu, m >> 16), active, Lnorm);
+        path_normalise<NP, PARTIAL>(Ln, min(m & 0xffffu, m >> 16), active, Lnorm);
         Pack<NP> Sn;
-        Sn.r[0] = MODE == PATH_FIRST ? Ln.r[0] : pk_adds_s(sv.r[0], Ln.r[0]);
+#pragma unroll
+        for (int i = 0; i < NP; i++) Sn.r[i] = MODE == PATH_FIRST ? Ln.r[i] : pk_adds_s(sv.r[i], Ln.r[i]);
         const int x = x0 + k * rx;
-        buf_store<NP>(Sn, Sst, voff, x * pxb);
+        if (stores_S) buf_store<NP>(Sn, Sst, voff, x * pxb);
         L = Lnorm;
         return Sn;
     };
@@ -83,14 +93,14 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
                 Sn[1] = pixel(cb[u0 + 1], sb[u0 + 1], k0 + u0 + 1);
                 if (MODE == PATH_LAST) {
                     uint2 *recs[2] = {wrow + (x0 + (k0 + u0) * rx), wrow + (x0 + (k0 + u0 + 1) * rx)};
-                    wta_pixels<NP, true, POSW, 2, GW>(Sn, lw, active, D, g.uniq, recs);
+                    wta_pixels<NP, PARTIAL, POSW, 2, GW>(Sn, lw, active, D, g.uniq, recs);
                 }
             } else if (k0 + u0 < W1) {
                 Pack<NP> Sn[1];
                 Sn[0] = pixel(cb[u0], sb[u0], k0 + u0);
                 if (MODE == PATH_LAST) {
                     uint2 *recs[1] = {wrow + (x0 + (k0 + u0) * rx)};
-                    wta_pixels<NP, true, POSW, 1, GW>(Sn, lw, active, D, g.uniq, recs);
+                    wta_pixels<NP, PARTIAL, POSW, 1, GW>(Sn, lw, active, D, g.uniq, recs);
                 }
             }
         }

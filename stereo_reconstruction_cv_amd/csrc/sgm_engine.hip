@@ -211,25 +211,30 @@ static int group_width(const Geom &g, int H)
     if (g.D > 64 || (int64_t)H * g.rowsz * 2 >= (int64_t)0x7fff0000) return 64;
     return g.D <= 16 ? 8 : (g.D <= 32 ? 16 : 32);
 }
-template <int GW>
+template <int GW, int NP, bool PARTIAL>
 static void launch_rows_g(const Geom &g, int H, int rx, int mode, const int16_t *C, int16_t *S, int keepS, uint2 *wta, hipStream_t st)
 {
     constexpr int G = 64 / GW;
     dim3 grid((H + G - 1) / G), block(64);
     if (mode == PATH_FIRST)
-        hipLaunchKernelGGL((k_rows_g<GW, PATH_FIRST, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
+        hipLaunchKernelGGL((k_rows_g<GW, NP, PARTIAL, PATH_FIRST, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
     else if (mode == PATH_ACCUM)
-        hipLaunchKernelGGL((k_rows_g<GW, PATH_ACCUM, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
+        hipLaunchKernelGGL((k_rows_g<GW, NP, PARTIAL, PATH_ACCUM, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
     else if (g.uniq < 100)
-        hipLaunchKernelGGL((k_rows_g<GW, PATH_LAST, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
+        hipLaunchKernelGGL((k_rows_g<GW, NP, PARTIAL, PATH_LAST, true>), grid, block, 0, st, g, rx, C, S, keepS, wta);
     else
-        hipLaunchKernelGGL((k_rows_g<GW, PATH_LAST, false>), grid, block, 0, st, g, rx, C, S, keepS, wta);
+        hipLaunchKernelGGL((k_rows_g<GW, NP, PARTIAL, PATH_LAST, false>), grid, block, 0, st, g, rx, C, S, keepS, wta);
 }
+// the in-row path of a pass (rows are independent): GW < 64 packs 64/GW rows into a wave
 static void launch_rows_grouped(const Geom &g, int H, int GW, int rx, int mode, const int16_t *C, int16_t *S, int keepS, uint2 *wta, hipStream_t st)
 {
-    if (GW == 8) launch_rows_g<8>(g, H, rx, mode, C, S, keepS, wta, st);
-    else if (GW == 16) launch_rows_g<16>(g, H, rx, mode, C, S, keepS, wta, st);
-    else launch_rows_g<32>(g, H, rx, mode, C, S, keepS, wta, st);
+    const bool partial = g.D != 128 * g.NP;
+    if (GW == 8) launch_rows_g<8, 1, true>(g, H, rx, mode, C, S, keepS, wta, st);
+    else if (GW == 16) launch_rows_g<16, 1, true>(g, H, rx, mode, C, S, keepS, wta, st);
+    else if (GW == 32) launch_rows_g<32, 1, true>(g, H, rx, mode, C, S, keepS, wta, st);
+    else if (g.NP == 1) { if (partial) launch_rows_g<64, 1, true>(g, H, rx, mode, C, S, keepS, wta, st); else launch_rows_g<64, 1, false>(g, H, rx, mode, C, S, keepS, wta, st); }
+    else if (g.NP == 2) { if (partial) launch_rows_g<64, 2, true>(g, H, rx, mode, C, S, keepS, wta, st); else launch_rows_g<64, 2, false>(g, H, rx, mode, C, S, keepS, wta, st); }
+    else { if (partial) launch_rows_g<64, 4, true>(g, H, rx, mode, C, S, keepS, wta, st); else launch_rows_g<64, 4, false>(g, H, rx, mode, C, S, keepS, wta, st); }
 }
 
 template <int NP, bool PARTIAL, int MODE, bool POSW>
@@ -609,8 +614,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 if ((rc = stage_begin(e, fused_wta ? "path_W_wta" : "path_W"))) return rc;
                 const int GW = (e->debug & 4) ? 64 : group_width(g, H);  // debug 4: no lane groups (A/B)
                 const int pm = fused_wta ? PATH_LAST : PATH_ACCUM;
-                if (GW < 64) launch_rows_grouped(g, H, GW, -1, pm, C, S, e->keep_aggr, wta, st);
-                else launch_path(g, -1, 0, pm, C, S, e->keep_aggr, wta, st);
+                if (GW == 64 && (e->debug & 4)) launch_path(g, -1, 0, pm, C, S, e->keep_aggr, wta, st);  // A/B: the general line kernel
+                else launch_rows_grouped(g, H, GW, -1, pm, C, S, e->keep_aggr, wta, st);
                 KCHECK();
                 if ((rc = stage_end(e, 1))) return rc;
             }
