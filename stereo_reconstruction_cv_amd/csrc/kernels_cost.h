@@ -489,6 +489,76 @@ __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restric
     }
 }
 
+// ---- small D (the engine uses these for D <= 32): one THREAD per pixel ----------------------------
+// With lanes spanning the disparities, D = 16 uses 8 of 64 lanes in k_hsum / k_pix.  Here a thread
+// owns a pixel and loops over its disparities; the right-image features of a 256-pixel block
+// (256 + D bytes per plane) are staged in LDS.  k_pix_px writes the per-pixel cost as bytes,
+// k_hsum_px turns it into the int16 horizontal box sums that k_vsum_ring (element-wise, any D)
+// finishes.  Same arithmetic as k_hsum (A.3, A.4).
+__global__ __launch_bounds__(256) void k_pix_px(Geom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rplanes,
+                                                uint8_t *__restrict__ pix)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t seg[];  // [6][256 + D]
+    const int t = threadIdx.x, y = blockIdx.y, b0 = blockIdx.x * 256;
+    const int W = g.W, W1 = g.W1, D = g.D, SL = 256 + D;
+    // mirrored position of (column xi, disparity index e): (W-1-(xi+minX1)) + minD + e; the block's
+    // smallest one belongs to xi = b0 + 255, e = 0
+    const int pmin = W - 1 - (b0 + 255 + g.minX1) + g.minD;
+    const int64_t psz = (int64_t)g.H * W;
+    for (int s = t; s < SL - 1; s += 256) {
+        const int pos = pmin + s;
+        const bool ok = pos >= 0 && pos < W;
+#pragma unroll
+        for (int c = 0; c < 6; c++) seg[c * SL + s] = ok ? rplanes[c * psz + (int64_t)y * W + pos] : (uint8_t)0;
+    }
+    __syncthreads();
+    const int xi = b0 + t;
+    if (xi >= W1) return;
+    const uint2 rec = lrec[(int64_t)y * W + xi + g.minX1];
+    const int U = rec.x & 0xff, U0 = (rec.x >> 8) & 0xff, U1 = (rec.x >> 16) & 0xff;
+    const int R = rec.y & 0xff, R0 = (rec.y >> 8) & 0xff, R1 = (rec.y >> 16) & 0xff;
+    const uint8_t *sp = seg + (255 - t);
+    uint32_t *out = reinterpret_cast<uint32_t *>(pix + ((int64_t)y * W1 + xi) * D);
+    for (int e0 = 0; e0 < D; e0 += 4) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = e0 + q;
+            const int V = sp[0 * SL + e], V0 = sp[1 * SL + e], V1 = sp[2 * SL + e];
+            const int Q = sp[3 * SL + e], Q0 = sp[4 * SL + e], Q1 = sp[5 * SL + e];
+            const int a = min(max(max(U - V1, V0 - U), 0), max(max(V - U1, U0 - V), 0));
+            const int b = min(max(max(R - Q1, Q0 - R), 0), max(max(Q - R1, R0 - Q), 0));
+            packed |= (uint32_t)(a + (b >> 2)) << (8 * q);
+        }
+        out[e0 / 4] = packed;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hsum_px(Geom g, const uint8_t *__restrict__ pix, int16_t *__restrict__ hsum)
+{
+    const int xi = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int W1 = g.W1, D = g.D, R = g.SW2;
+    if (xi >= W1) return;
+    const uint8_t *row = pix + (int64_t)y * W1 * D;
+    uint32_t *out = reinterpret_cast<uint32_t *>(hsum + ((int64_t)y * W1 + xi) * D);
+    for (int e0 = 0; e0 < D; e0 += 16) {  // 16 disparities = one 16-byte vector per neighbour
+        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int tt = -R; tt <= R; tt++) {
+            const int xc = min(max(xi + tt, 0), W1 - 1);
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + (int64_t)xc * D + e0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc[2 * k] = pk_add(acc[2 * k], __builtin_amdgcn_perm(0u, w[k], 0x0c010c00u));
+                acc[2 * k + 1] = pk_add(acc[2 * k + 1], __builtin_amdgcn_perm(0u, w[k], 0x0c030c02u));
+            }
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(out + e0 / 2);
+        o[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        o[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 // C(y) = sum_{j=-SH2..SH2} hsum(clamp(y+j, 0, H-1)), running along y inside a band of rows.
 __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
                                               int H, int64_t rowsz, int SH2, int RB)

@@ -461,7 +461,16 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             if ((rc = stage_end(e, 1))) return rc;
         } else {
         if ((rc = stage_begin(e, "cost_hsum"))) return rc;
-        if ((rc = launch_hsum(0, H))) return rc;
+        if (g.D <= 32 && !(e->debug & 4) && 2 * g.ftzero + 63 <= 255) {
+            // D <= 32: one thread per pixel (lanes spanning D would mostly idle; at D = 64 the wave-per-
+            // chunk kernel is still ahead); the byte volume borrows the S buffer, unused before the paths
+            uint8_t *px = (uint8_t *)e->aggr.p;
+            dim3 grid((g.W1 + 255) / 256, H), block(256);
+            hipLaunchKernelGGL(k_pix_px, grid, block, (size_t)6 * (256 + g.D), st, g, lrec, rpl, px);
+            hipLaunchKernelGGL(k_hsum_px, grid, block, 0, st, g, (const uint8_t *)px, (int16_t *)HS);
+        } else if ((rc = launch_hsum(0, H))) {
+            return rc;
+        }
         KCHECK();
         if ((rc = stage_end(e, 1))) return rc;
         if ((rc = stage_begin(e, "cost_vsum"))) return rc;
