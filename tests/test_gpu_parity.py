@@ -256,7 +256,7 @@ def test_uniqueness_ratio_edges(uniq):
         assert not bad, f"uniq={uniq} mode={mode}: " + "\n".join(bad)
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,W", [(512, 1100), (256, 700)])
+@pytest.mark.parametrize("D,W", [(512, 1100), (256, 700), (32, 300), (16, 250)])
 def test_fused_sweeps_repeatable(D, W):
     """Run the same frame many times: every run must reproduce the per-direction schedule's S and
     disparity bit for bit.  (Round 1: with D = 512 the fused sweeps' 128-bit S stores picked up
