@@ -87,7 +87,8 @@ def geometry(p: Params, W: int):
 def sgbm_compute(left: np.ndarray, right: np.ndarray, taps: bool = False, **kw):
     """stereo.compute(left, right) of main.ipynb:668 -> int16 (H, W).
 
-    With taps=True also returns a dict with C, S, disp_raw, disp_median and the headroom record.
+    With taps=True also returns a dict with C, S, disp_raw, disp_median and the headroom record;
+    taps="light" leaves out the two volumes (full-size frames: 4 GB each at 4K, D=256).
     """
     p = kw.pop("params", None) or make_params(**kw)
     left = np.ascontiguousarray(left, dtype=np.uint8)
@@ -100,7 +101,7 @@ def sgbm_compute(left: np.ndarray, right: np.ndarray, taps: bool = False, **kw):
     if taps:
         _, W1 = geometry(p, W)
         D = p.numDisparities
-        if W1 > 0:
+        if W1 > 0 and taps != "light":
             out["C"] = np.zeros((H, W1, D), np.int16)
             out["S"] = np.zeros((H, W1, D), np.int16)
             t.C = out["C"].ctypes.data

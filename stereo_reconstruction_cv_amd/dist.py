@@ -7,7 +7,7 @@ single-process notebook, main.ipynb:780-797).
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Sequence, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -85,11 +85,11 @@ def gather_results(local: torch.Tensor, n_frames: int, dst: int = 0, group=None)
     return out
 
 
-def run_sharded(compute: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], lefts: Optional[torch.Tensor],
-                rights: Optional[torch.Tensor], src: int = 0, device: Optional[torch.device] = None,
-                group=None) -> Optional[torch.Tensor]:
+def run_sharded(compute: Callable, lefts: Optional[torch.Tensor], rights: Optional[torch.Tensor], src: int = 0,
+                device: Optional[torch.device] = None, group=None):
     """scatter -> compute(local_lefts, local_rights) -> gather.  `compute` maps [n, H, W] u8 pairs
-    to [n, ...] results on the same device (on the GPU box: the HIP engine's batch entry)."""
+    to [n, ...] results on the same device (on the GPU box: the HIP engine's batch entry); it may
+    return one tensor or a tuple of tensors (disparity, XYZ), each gathered to `src` in turn."""
     rank, world = _world(group)
     n_meta = [int(lefts.shape[0]) if rank == src and lefts is not None else 0]
     if world > 1:
@@ -97,24 +97,46 @@ def run_sharded(compute: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], l
     l = scatter_frames(lefts, src, device, group)
     r = scatter_frames(rights, src, device, group)
     res = compute(l, r)
+    if isinstance(res, (tuple, list)):
+        outs = [gather_results(t, n_meta[0], src, group) for t in res]
+        return tuple(outs) if rank == src or world == 1 else None
     return gather_results(res, n_meta[0], src, group)
 
 
-def hip_batch_compute(params: dict, Q=None) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
-    """compute() for run_sharded backed by the HIP engine on this rank's GPU (device tensors in,
-    int16 disparities out; with Q also returns XYZ through a second tensor attribute)."""
+def hip_batch_compute(params: dict, Q=None, want_float: bool = False) -> Callable:
+    """compute() for run_sharded backed by the HIP engine on this rank's GPU: device tensors
+    [n, H, W] u8 in, int16 disparities [n, H, W] out.  With Q (4x4) the whole driver cell runs per
+    frame (sgm_pipeline_device: compute -> float scaling -> reprojectImageTo3D,
+    main.ipynb:780-797) and compute returns (disparity int16, XYZ float32 [n, H, W, 3])
+    -- plus the float disparity [n, H, W] in between when want_float is set."""
+    import numpy as np
+
     from . import stereo as _cv
 
-    def compute(lefts: torch.Tensor, rights: torch.Tensor) -> torch.Tensor:
-        if not lefts.is_cuda:
+    Qm = None if Q is None else np.ascontiguousarray(np.asarray(Q, dtype=np.float64).reshape(4, 4))
+
+    def compute(lefts: torch.Tensor, rights: torch.Tensor):
+        if not lefts.is_cuda or not rights.is_cuda:
             raise _cv.error("hip_batch_compute needs device tensors (there is no CPU fallback)")
+        if lefts.shape != rights.shape or lefts.dim() != 3 or lefts.dtype != torch.uint8 or rights.dtype != torch.uint8:
+            raise _cv.error("hip_batch_compute: lefts/rights must be uint8 [n, H, W] of equal shape")
+        lefts, rights = lefts.contiguous(), rights.contiguous()
         n, H, W = lefts.shape
-        eng = _cv.get_engine(params, lefts.device.index or 0)
-        out = torch.empty((n, H, W), dtype=torch.int16, device=lefts.device)
-        torch.cuda.current_stream(lefts.device).synchronize()
+        dev = lefts.device
+        eng = _cv.get_engine(params, dev.index or 0)
+        disp = torch.empty((n, H, W), dtype=torch.int16, device=dev)
+        dispf = torch.empty((n, H, W), dtype=torch.float32, device=dev) if Qm is not None else None
+        xyz = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev) if Qm is not None else None
+        torch.cuda.current_stream(dev).synchronize()  # the engine runs on its own stream
         for i in range(n):
-            eng.compute_device(lefts[i].data_ptr(), rights[i].data_ptr(), H, W, W, out[i].data_ptr())
+            if Qm is None:
+                eng.compute_device(lefts[i].data_ptr(), rights[i].data_ptr(), H, W, W, disp[i].data_ptr())
+            else:
+                eng.pipeline_device(lefts[i].data_ptr(), rights[i].data_ptr(), H, W, W, Qm, disp[i].data_ptr(),
+                                    dispf[i].data_ptr(), xyz[i].data_ptr())
         eng.synchronize()
-        return out
+        if Qm is None:
+            return disp
+        return (disp, dispf, xyz) if want_float else (disp, xyz)
 
     return compute

@@ -11,8 +11,12 @@ from stereo_reconstruction_cv_amd.stereo import Engine
 NB = dict(disp12MaxDiff=1, preFilterCap=63, uniquenessRatio=10, speckleWindowSize=100, speckleRange=32)
 
 
-def params(D, bs, minD=0, mode=0, **kw):
-    p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=8 * bs * bs, P2=32 * bs * bs, mode=mode, **NB)
+def params(D, bs, minD=0, mode=0, penalty="notebook", **kw):
+    """Notebook penalties by default (/root/reference/main.ipynb:659-660: P1 = 8*3*bs^2, P2 = 32*3*bs^2,
+    the 3-channel formula on grayscale input -- what bench.py times); penalty="plain" gives the
+    single-channel 8*bs^2 / 32*bs^2 of OpenCV's documentation."""
+    ch = 3 if penalty == "notebook" else 1
+    p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=8 * ch * bs * bs, P2=32 * ch * bs * bs, mode=mode, **NB)
     p.update(kw)
     return p
 

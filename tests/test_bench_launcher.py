@@ -1,0 +1,58 @@
+"""bench.py's own launcher and multi-rank plumbing on a box without a GPU (BENCH_MOCK=1 swaps the
+HIP engine for a stand-in and the rendezvous runs over gloo): `python bench.py --gpus N` started
+plainly must spawn its N ranks, shard the frames, bracket the timed region with barriers, push one
+batch through dist.scatter_frames / gather_results and print exactly one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, n=2):
+    env = dict(os.environ, BENCH_MOCK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "tiny",
+                        "--steps", "2", "--warmup", "1", *extra], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                    # ONE JSON line, nothing else on stdout
+    return json.loads(lines[0])
+
+
+def test_plain_start_with_two_gpus_launches_its_own_ranks():
+    d = _run()
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["world_size"] == 2 and d["config"]["frames_per_rank"] == [2, 2]
+    assert d["config"]["global_pairs_per_step"] == 4 and d["config"]["ingest"] == "resident"
+    # the default run also exercises scatter -> compute -> gather once, outside the timed region
+    assert d["rccl_ingest_check"]["ok"] is True and d["rccl_ingest_check"]["frames"] == 4
+    assert "BENCH_MOCK" in d["data"]
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "roofline"):
+        assert k in d
+
+
+def test_rank0_ingest_mode_three_ranks():
+    d = _run("--ingest", "rank0", n=3)
+    assert d["n_gpus"] == 3 and d["config"]["ingest"] == "rank0"
+    assert d["config"]["frames_per_rank"] == [2, 2, 2]
+    assert "rank 0 scatters" in d["config"]["parallelism"]
+
+
+def test_single_gpu_path_needs_no_launcher():
+    d = _run(n=1)
+    assert d["n_gpus"] == 1 and d["config"]["world_size"] == 1 and "rccl_ingest_check" not in d
+
+
+def test_without_the_mock_and_without_a_gpu_it_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = {k: v for k, v in os.environ.items() if k not in ("BENCH_MOCK", "RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)

@@ -37,6 +37,12 @@ def _fake_compute(l, r):
     return (l.to(torch.int16) * 3 - r.to(torch.int16)).contiguous()
 
 
+def _fake_compute_pair(l, r):
+    # (disparity, XYZ)-shaped result: two tensors of different dtype and rank per frame
+    d = _fake_compute(l, r)
+    return d, torch.stack([d.float(), d.float() * 0.5, d.float() + 1.0], dim=-1)
+
+
 def _worker(rank, world, port, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -47,8 +53,13 @@ def _worker(rank, world, port, n, q):
         rights = torch.randint(0, 256, (n, 6, 10), dtype=torch.uint8, generator=g)
         out = D.run_sharded(_fake_compute, lefts if rank == 0 else None, rights if rank == 0 else None)
         lo, hi = D.shard_range(n, rank, world)
+        both = D.run_sharded(_fake_compute_pair, lefts if rank == 0 else None, rights if rank == 0 else None)
         if rank == 0:
+            want_d, want_x = _fake_compute_pair(lefts, rights)
+            assert isinstance(both, tuple) and torch.equal(both[0], want_d) and torch.equal(both[1], want_x)
             q.put(("result", out.numpy(), _fake_compute(lefts, rights).numpy()))
+        else:
+            assert both is None
         q.put(("span", rank, lo, hi))
         dist.barrier()
     finally:

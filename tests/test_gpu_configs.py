@@ -1,0 +1,176 @@
+"""Every BASELINE.json config at FULL size, with the benchmark's own parameters and entry points,
+bit-exact against the CPU oracle (needs an MI355X; the oracle side costs about a minute in all).
+
+Parameters follow the notebook call (/root/reference/main.ipynb:655-666): P1 = 8*3*bs^2,
+P2 = 32*3*bs^2, disp12MaxDiff=1, preFilterCap=63, uniquenessRatio=10, speckleWindowSize=100,
+speckleRange=32; inputs are the bench's synthetic pairs (synth.make_pair(seed=1234 + i),
+SURVEY.md 8d).  Entry points are the ones bench.py times: sgm_pipeline_device for the single
+frames, sgm_compute_batch and dist.hip_batch_compute for the batch config.
+
+Parity statement: bit-exact vs. a restatement of OpenCV 4.11 MODE_SGBM / MODE_HH inside the int16
+no-overflow regime (the oracle is unpinned against cv2); XYZ: identical non-finite
+masks and 1e-4 relative on finite values (north_star's tolerance; the kernel is in fact bit-exact).
+"""
+import functools
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from stereo_reconstruction_cv_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+NB = dict(disp12MaxDiff=1, preFilterCap=63, uniquenessRatio=10, speckleWindowSize=100, speckleRange=32)
+
+
+def nb_params(D, bs, mode):
+    return dict(minDisparity=0, numDisparities=D, blockSize=bs, P1=8 * 3 * bs * bs, P2=32 * 3 * bs * bs, mode=mode, **NB)
+
+
+@functools.lru_cache(maxsize=2)
+def pair(H, W, D, seed):
+    l, r, _ = synth.make_pair(H, W, D, seed)
+    return l, r
+
+
+def oracle_frame(l, r, p, Q=None):
+    want, t = O.sgbm_compute(l, r, taps="light", **p)
+    assert t["headroom_ok"], "synthetic input left the int16 no-overflow regime"
+    if Q is None:
+        return want, None, None
+    f = O.disp_to_float(want)
+    return want, f, O.reproject(f, Q)
+
+
+def check_xyz(got, ref):
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin), "non-finite masks differ"
+    # tolerance from BASELINE.json north_star: 1e-4 relative
+    assert np.allclose(got[fin], ref[fin], rtol=1e-4, atol=0.0)
+    assert np.array_equal(got[fin], ref[fin])   # and in fact bit-exact
+
+
+def run_pipeline_device(l, r, p, Q):
+    """The call bench.py times: device-resident inputs -> sgm_pipeline_device."""
+    import torch
+    import stereo_reconstruction_cv_amd as cv
+    H, W = l.shape
+    dev = torch.device("cuda", 0)
+    dl, dr = torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)
+    dd = torch.empty((H, W), dtype=torch.int16, device=dev)
+    df = torch.empty((H, W), dtype=torch.float32, device=dev) if Q is not None else None
+    dx = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if Q is not None else None
+    torch.cuda.synchronize(dev)
+    eng = cv.Engine(p, device=0)
+    eng.set_option(_lib.SGM_OPT_PROFILE, 1)   # as the bench does
+    for _ in range(2):   # twice: buffer reuse across frames is part of what the bench runs
+        eng.pipeline_device(dl.data_ptr(), dr.data_ptr(), H, W, W, Q, dd.data_ptr(),
+                            df.data_ptr() if Q is not None else None, dx.data_ptr() if Q is not None else None)
+        eng.synchronize()
+    names = [n for n, _, _ in eng.stage_times()]
+    out = dd.cpu().numpy(), (df.cpu().numpy() if Q is not None else None), (dx.cpu().numpy() if Q is not None else None)
+    del eng
+    return out + (names,)
+
+
+def test_c1_720p_d64_host_entry():
+    """configs[0]: single 1280x720 pair, D=64, blockSize=5, through the cv2-shaped host call."""
+    import stereo_reconstruction_cv_amd as cv
+    H, W, D, bs = 720, 1280, 64, 5
+    l, r = pair(H, W, D, 1234)
+    p = nb_params(D, bs, 0)
+    want, _, _ = oracle_frame(l, r, p)
+    got = cv.StereoSGBM_create(**p).compute(l, r)
+    assert got.dtype == np.int16 and got.shape == (H, W)
+    assert int((got != want).sum()) == 0
+    assert (got >= 0).mean() > 0.5
+    got2, _, _, _ = run_pipeline_device(l, r, p, None)
+    assert int((got2 != want).sum()) == 0
+
+
+def test_c2_4k_d128_pipeline_device():
+    """configs[1]: single 3840x2160 pair, D=128, blockSize=7, 5 paths."""
+    H, W, D, bs = 2160, 3840, 128, 7
+    l, r = pair(H, W, D, 1234)
+    p = nb_params(D, bs, 0)
+    want, _, _ = oracle_frame(l, r, p)
+    got, _, _, names = run_pipeline_device(l, r, p, None)
+    assert int((got != want).sum()) == 0, f"{int((got != want).sum())} of {got.size} differ"
+    assert "sweep_dn" in names      # the fused-sweep schedule ran (not a fallback)
+
+
+def test_c3_c5_4k_d256_hh_pipeline_device_with_xyz():
+    """configs[2] + configs[4] = bench.py's default workload c3c5: 3840x2160, D=256, MODE_HH (8
+    paths) + LR + sub-pixel + median + speckle + reprojectImageTo3D through sgm_pipeline_device."""
+    H, W, D, bs = 2160, 3840, 256, 7
+    l, r = pair(H, W, D, 1234)
+    p = nb_params(D, bs, 1)
+    Q = synth.default_Q(W)
+    want, wf, wxyz = oracle_frame(l, r, p, Q)
+    got, gf, gxyz, names = run_pipeline_device(l, r, p, Q)
+    assert int((got != want).sum()) == 0, f"{int((got != want).sum())} of {got.size} differ"
+    assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32))      # incl. the sign of zero
+    check_xyz(gxyz, wxyz)
+    assert {"sweep_dn", "sweep_up", "wta", "reproject"} <= set(names)
+
+
+def test_c5_4k_d256_5path_pipeline_device_with_xyz():
+    """configs[4] as the notebook would run it (default mode = 5 paths) + XYZ."""
+    H, W, D, bs = 2160, 3840, 256, 7
+    l, r = pair(H, W, D, 1234)
+    p = nb_params(D, bs, 0)
+    Q = synth.default_Q(W)
+    want, wf, wxyz = oracle_frame(l, r, p, Q)
+    got, gf, gxyz, _ = run_pipeline_device(l, r, p, Q)
+    assert int((got != want).sum()) == 0, f"{int((got != want).sum())} of {got.size} differ"
+    assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32))
+    check_xyz(gxyz, wxyz)
+
+
+def test_c4_batch_1080p_d128_both_batch_entries():
+    """configs[3], one GPU's share reduced to 5 frames (odd: the two engines of the two-in-flight
+    batch path end differently): sgm_compute_batch (host pointers, XYZ) and dist.hip_batch_compute
+    (device tensors, XYZ) -- the entry the sharded multi-GPU path calls on every rank."""
+    import torch
+    import stereo_reconstruction_cv_amd as cv
+    from stereo_reconstruction_cv_amd import dist as D_
+    H, W, D, bs, N = 1080, 1920, 128, 7, 5
+    p = nb_params(D, bs, 0)
+    Q = synth.default_Q(W)
+    frames = [synth.make_pair(H, W, D, 1234 + i)[:2] for i in range(N)]
+    L = np.stack([a for a, _ in frames])
+    R = np.stack([b for _, b in frames])
+    wants = [oracle_frame(L[i], R[i], p, Q) for i in range(N)]
+    eng = cv.get_engine(p)
+    disps, xyz = eng.compute_batch_host(L, R, Q)
+    for i in range(N):
+        assert int((disps[i] != wants[i][0]).sum()) == 0, i
+        check_xyz(xyz[i], wants[i][2])
+    compute = D_.hip_batch_compute(p, Q, want_float=True)
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    d2, f2, x2 = compute(dl, dr)
+    assert d2.is_cuda and d2.dtype == torch.int16 and x2.shape == (N, H, W, 3)
+    d2, f2, x2 = d2.cpu().numpy(), f2.cpu().numpy(), x2.cpu().numpy()
+    for i in range(N):
+        assert int((d2[i] != wants[i][0]).sum()) == 0, i
+        assert np.array_equal(f2[i].view(np.uint32), wants[i][1].view(np.uint32))
+        check_xyz(x2[i], wants[i][2])
+    d3 = D_.hip_batch_compute(p)(dl[:2], dr[:2]).cpu().numpy()     # without Q: disparities only
+    assert np.array_equal(d3, d2[:2])
+
+
+def test_notebook_setting_4k_d16_bs11():
+    """The notebook as run (main.ipynb:781: ndisp=16, mindis=0, blockSize=11) on a 4K synthetic
+    pair through the notebook-shaped functions.  bs=11 / P2=11616 is outside the worst-case
+    headroom bound; the oracle confirms this input stays inside the regime."""
+    import stereo_reconstruction_cv_amd as cv
+    H, W, D = 2160, 3840, 16
+    l, r = pair(H, W, D, 1234)
+    p = nb_params(D, 11, 0)
+    Q = synth.default_Q(W)
+    want, wf, wxyz = oracle_frame(l, r, p, Q)
+    disp, pts, mask = cv.run_disparity(l, r, Q, 16, 0)
+    assert np.array_equal(disp.view(np.uint32), wf.view(np.uint32))
+    check_xyz(pts, wxyz)
+    assert np.array_equal(mask, O.valid_mask(wxyz, wf))
