@@ -477,7 +477,7 @@ def main():
         out["speedup_vs_cpu_baseline"] = mdisp / out["cpu_baseline"]["value"]
         # frame-parallel: `usable` threads, each one frame-sample of its own (ctypes releases the GIL)
         nthreads = max(1, min(usable, 64))
-        prow = max(32, min(rows, int(rows * 4.0 / max(cdt, 1e-3))))   # about 4 s per thread
+        prow = max(32, min(rows, int(rows * 1.0 / max(cdt, 1e-3))))   # about 1 s per thread alone (several when all contend for memory)
         pl, pr = pairs[0][0][:prow], pairs[0][1][:prow]
 
         def one(_):

@@ -241,13 +241,28 @@ __device__ __forceinline__ void buf_store(const Pack<NP> &p, __amdgpu_buffer_rsr
         v.x = p.r[0];
         v.y = p.r[1];
         __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff_bytes, soff_bytes, 0);
+#ifdef SGM_EXPERIMENT_STORE_X4  // ISA study only; never defined in a shipped build
+    } else if constexpr (NP == 4) {
+        v4u32 v;
+        v.x = p.r[0];
+        v.y = p.r[1];
+        v.z = p.r[2];
+        v.w = p.r[3];
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff_bytes, soff_bytes, 0);
+#endif
     } else {
-        // Two 64-bit stores, never buffer_store_dwordx4.  Round 1 found (MI355X, ROCm 7.2) that a
-        // buffer_store_dwordx4 with an SGPR soffset can pick up a later value of its data VGPRs
-        // when those are rewritten before the wave's next long wait: now and then dword 0 of
-        // lanes 12-15 of every 16 came out wrong in the stored S (NP = 4 sweeps; the compiler
-        // sees no hazard for this form and inserts nothing).  The 64-bit form has never shown
-        // it.  The empty asm keeps the two halves from being merged again.
+        // Two 64-bit stores, never buffer_store_dwordx4 (root cause found in round 2).
+        // A MUBUF store of more than 64 bits reads its upper data registers a cycle or two after
+        // issue: a VALU write to them needs 1-2 wait states behind the store.  hipcc (ROCm 7.2,
+        // GCNHazardRecognizer::createsVALUHazard) pads that hazard only when soffset is an
+        // immediate; with an SGPR soffset -- every store here -- it pads nothing, and in k_sweep it
+        // scheduled "buffer_store_dwordx4 v[12:15], .., s35 offen" directly in front of
+        // "v_perm_b32 v12, .." (the first instruction of the next min-reduction).  Under memory
+        // back-pressure the store then picked up the new v12 in the last quad of every row of 16
+        // lanes: exactly the wrong S dwords seen in round 1 (the stored value is the per-lane
+        // partial minimum the reduction starts from).  64-bit stores read all their data at issue
+        // and have no such hazard.  The empty asm keeps the two halves from being merged again;
+        // tests/test_abi.py checks the generated ISA for buffer_store_dwordx3/x4.
         v2u32 lo, hi;
         lo.x = p.r[0];
         lo.y = p.r[1];

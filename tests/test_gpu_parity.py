@@ -48,7 +48,7 @@ def test_every_stage_bit_exact(H, W, D, bs, minD, mode, seed):
 def test_every_stage_bit_exact_per_direction_schedule(H, W, D, bs, minD, mode, seed):
     """schedule 0: one k_path launch per direction"""
     l, r, _ = synth.make_pair(H, W, D, seed)
-    p = U.params(D, bs, minD, mode, speckleWindowSize=30, speckleRange=2)
+    p = U.params(D, bs, minD, mode, penalty="plain", speckleWindowSize=30, speckleRange=2)   # single-channel 8 / 32 bs^2
     rep, t, h = U.compare_stages(l, r, p, schedule=0)
     bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
     assert not bad, "\n".join(bad)
@@ -258,15 +258,16 @@ def test_uniqueness_ratio_edges(uniq):
 @pytest.mark.gpu
 @pytest.mark.parametrize("D,W", [(512, 1100), (256, 700), (32, 300), (16, 250)])
 def test_fused_sweeps_repeatable(D, W):
-    """Run the same frame many times: every run must reproduce the per-direction schedule's S and
-    disparity bit for bit.  (Round 1: with D = 512 the fused sweeps' 128-bit S stores picked up
-    later register contents now and then -- about one run in two had a few wrong S vectors; see
-    DESIGN.md 4.3.  A single comparison per case would pass half of the time.)"""
+    """The fused sweeps must reproduce the per-direction schedule's S and disparity bit for bit,
+    also when the same frame is run again.  (Round 1: with D = 512 the 128-bit S stores picked up
+    later register contents now and then.  Root cause, round 2: a VMEM-store data hazard hipcc does
+    not pad for MUBUF stores with an SGPR soffset -- DESIGN.md 4.3; the guard against it is the ISA
+    check in tests/test_abi.py, not repetition; three runs here only keep the symptom in sight.)"""
     H = 20
     l, r, _ = synth.make_pair(H, W, D, 11)
     p = U.params(D, 3, 0, 1, speckleWindowSize=30, speckleRange=2)
     ref = U.run_hip_with_taps(l, r, p, schedule=0)
-    for trial in range(12):
+    for trial in range(3):
         for rows in (0, 1, 3):
             h = U.run_hip_with_taps(l, r, p, schedule=1, sweep_rows=rows)
             assert np.array_equal(h["S"], ref["S"]), (trial, rows)
