@@ -131,6 +131,16 @@ int sgm_median3x3(sgm_engine *e, const int16_t *src, int H, int W, int16_t *dst)
 int sgm_filter_speckles(sgm_engine *e, int16_t *img /* in place */, int H, int W, int newVal,
                         int maxSpeckleSize, int maxDiff);
 int sgm_get_tap(sgm_engine *e, int tap, void *host_dst, int64_t bytes);
+/* Regime record of the last compute (blocks on the engine's stream).  OpenCV 4.11's StereoSGBM
+ * (behind stereo.compute, /root/reference/main.ipynb:668) keeps C + P2 and min_d L_r + P2 in int16
+ * lanes with a mix of wrapping, truncating and saturating arithmetic; its results are exact integer
+ * arithmetic -- and this engine's results are claimed bit-exact -- only while both stay <= 32767
+ * (SURVEY.md A.9).  The kernels record both maxima on the device:
+ *   *max_cost_plus_p2 = P2 + max of the block cost, including the running-sum intermediate
+ *                       C(y-1) + hsum(y+r) upstream forms;   *max_delta = P2 + max over pixels and
+ *   directions of min_d L_r(p, d);   *ok = 1 iff both fit.  The notebook's own setting
+ *   (blockSize=11, P2=11616, main.ipynb:655-666) CAN leave the regime on high-contrast input. */
+int sgm_get_headroom(sgm_engine *e, int *max_cost_plus_p2, int *max_delta, int *ok);
 
 /* Rectification in front of the path.
  * K: 3x3 row-major.  dist: NULL or ndist in {4,5,8,12} coefficients (k1 k2 p1 p2 [k3 [k4 k5 k6

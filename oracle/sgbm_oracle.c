@@ -279,6 +279,9 @@ static inline int path_step(const int16_t *Cp, const int16_t *Lq, int mq, int P1
         acc[d] += L;
         mn = imin(mn, L);
     }
+    /* min_d L_r(p, .) + P2 is the next step's delta; recorded for every pixel (also the last of a
+     * line, where no successor forms it) so that the record does not depend on the scan order */
+    if (mn + P2 > *max_delta) *max_delta = mn + P2;
     return mn;
 }
 
@@ -523,7 +526,7 @@ int oracle_sgbm_compute(const oracle_sgbm_params *p, const uint8_t *left, const 
     oracle_median3x3_i16(tmp, disp, H, W);
     free(tmp);
     if (taps && taps->disp_median) memcpy(taps->disp_median, disp, (size_t)n * sizeof(int16_t));
-    if (p->speckleWindowSize > 0)
+    if (p->speckleRange >= 0 && p->speckleWindowSize > 0) /* upstream's condition (stereosgbm.cpp, StereoSGBMImpl::compute) */
         oracle_filter_speckles_i16(disp, H, W, (p->minDisparity - 1) * DISP_SCALE, p->speckleWindowSize,
                                    DISP_SCALE * p->speckleRange);
     return 0;

@@ -24,6 +24,13 @@
  * "bit-exact vs. a restatement of OpenCV 4.11 MODE_SGBM / MODE_HH inside the int16
  * no-overflow regime", never "bit-exact vs. the cv2 wheel".
  *
+ * One place where no parity is definable: upstream's first element of the horizontal running sum
+ * reads pixDiff[x + d] for x <= SW2*D without clamping x to width1 - 1.  When width1 <= SW2 (fewer
+ * matchable columns than the window radius) that read runs past the row upstream allocated
+ * (undefined); this restatement clamps the column to width1 - 1 (sgbm_oracle.c, hsum_row), which is
+ * what the definition of A.4 says.  Every frame with width1 > SW2 is unaffected.
+ * Also: filterSpeckles runs only if speckleRange >= 0 && speckleWindowSize > 0, as upstream.
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
 #ifndef SGBM_ORACLE_H
@@ -58,7 +65,7 @@ typedef struct {
     int16_t *disp_median; /* [H][W] after the 3x3 median, before the speckle filter */
     /* outputs: largest value any int16-typed intermediate of upstream would have held */
     int32_t max_cost_plus_p2;   /* max C_true + P2 (and the running-sum intermediate)   */
-    int32_t max_delta;          /* max P2 + min_d L_r(q, d)                               */
+    int32_t max_delta;          /* max P2 + min_d L_r(p, d) over all pixels and directions */
     int32_t headroom_ok;        /* 1 iff both stayed <= 32767             */
 } oracle_sgbm_taps;
 

@@ -21,7 +21,7 @@ SGM_MAX_STAGES = 32
 EXPORTS = (
     "sgm_abi_version", "sgm_device_count", "sgm_last_error", "sgm_create", "sgm_destroy",
     "sgm_set_option", "sgm_geometry", "sgm_compute", "sgm_compute_batch", "sgm_disp_to_float",
-    "sgm_reproject", "sgm_valid_mask", "sgm_get_tap", "sgm_median3x3", "sgm_filter_speckles", "sgm_compact_points",
+    "sgm_reproject", "sgm_valid_mask", "sgm_get_tap", "sgm_get_headroom", "sgm_median3x3", "sgm_filter_speckles", "sgm_compact_points",
     "sgm_compact_points_device", "sgm_compute_device",
     "sgm_disp_to_float_device", "sgm_reproject_device", "sgm_valid_mask_device",
     "sgm_pipeline_device", "sgm_synchronize", "sgm_get_stage_times", "sgm_algorithmic_bytes",
@@ -74,6 +74,7 @@ def load():
     L.sgm_reproject.argtypes = [vp, vp, i32, i32, vp, i32, vp]
     L.sgm_valid_mask.argtypes = [vp, vp, vp, i64, vp]
     L.sgm_get_tap.argtypes = [vp, i32, vp, i64]
+    L.sgm_get_headroom.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.sgm_median3x3.argtypes = [vp, vp, i32, i32, vp]
     L.sgm_filter_speckles.argtypes = [vp, vp, i32, i32, i32, i32, i32]
     L.sgm_compact_points.argtypes = [vp, vp, vp, vp, i64, vp, vp, C.POINTER(i64)]

@@ -29,6 +29,7 @@ struct Geom {
     int mode;
     int NP;       // packed pairs per lane
     int64_t rowsz;  // W1 * D
+    uint32_t *hr;   // headroom record of this compute (sgm_device.h: headroom_commit_pk), may be null
 };
 
 // ------------------------------------------------------------------------------------------
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restric
         }
     };
     uint32_t ring[RS][XC][NP], acc[XC][NP], hs[XC][NP];
+    uint32_t hmax = 0;  // packed running maximum of every int16 lane upstream would hold (headroom record)
 #pragma unroll
     for (int c = 0; c < XC; c++)
 #pragma unroll
@@ -470,6 +472,12 @@ __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restric
         }
     };
     put(y0);
+    // upstream reaches the first row of a band through C(y0-1) + hsum(y0+R) = C(y0) + hsum(y0-R-1)
+    if (y0 > 0) hsum_row(y0 - R - 1, hs);
+#pragma unroll
+    for (int c = 0; c < XC; c++)
+#pragma unroll
+        for (int i = 0; i < NP; i++) hmax = pk_max_u(hmax, y0 > 0 ? pk_add(acc[c][i], hs[c][i]) : acc[c][i]);
     for (int yb = y0; yb < y1; yb += RS) {
 #pragma unroll
         for (int u = 0; u < RS; u++) {
@@ -480,13 +488,17 @@ __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restric
                 for (int c = 0; c < XC; c++)
 #pragma unroll
                     for (int i = 0; i < NP; i++) {
-                        acc[c][i] = pk_sub(pk_add(acc[c][i], hs[c][i]), ring[(u - R - 1) & (RS - 1)][c][i]);
+                        const uint32_t t = pk_add(acc[c][i], hs[c][i]);  // C(y-1) + hsum(y+R): an int16 lane upstream
+                        hmax = pk_max_u(hmax, t);
+                        acc[c][i] = pk_sub(t, ring[(u - R - 1) & (RS - 1)][c][i]);
                         ring[(u + R) & (RS - 1)][c][i] = hs[c][i];
                     }
                 put(y);
             }
         }
     }
+    if (!active) hmax = 0;
+    headroom_commit_pk(g.hr, 0, hmax);
 }
 
 // ---- small D (the engine uses these for D <= 32): one THREAD per pixel ----------------------------
@@ -561,10 +573,11 @@ __global__ __launch_bounds__(256) void k_hsum_px(Geom g, const uint8_t *__restri
 
 // C(y) = sum_{j=-SH2..SH2} hsum(clamp(y+j, 0, H-1)), running along y inside a band of rows.
 __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
-                                              int H, int64_t rowsz, int SH2, int RB)
+                                              int H, int64_t rowsz, int SH2, int RB, uint32_t *hr)
 {
     const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;  // 8 int16 per thread
-    if (e >= rowsz) return;
+    uint32_t hmax = 0;
+    if (e < rowsz) {
     const int y0 = blockIdx.y * RB, y1 = min(y0 + RB, H);
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (int j = -SH2; j <= SH2; j++) {
@@ -573,13 +586,22 @@ __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, in
         acc.x = pk_add(acc.x, v.x); acc.y = pk_add(acc.y, v.y); acc.z = pk_add(acc.z, v.z); acc.w = pk_add(acc.w, v.w);
     }
     *reinterpret_cast<uint4 *>(C + (int64_t)y0 * rowsz + e) = acc;
+    {   // headroom record: the first row of a band as upstream reaches it, C(y0) + hsum(y0-SH2-1)
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (y0 > 0) b = *reinterpret_cast<const uint4 *>(hs + (int64_t)max(y0 - SH2 - 1, 0) * rowsz + e);
+        hmax = pk_max_u(pk_max_u(pk_add(acc.x, b.x), pk_add(acc.y, b.y)), pk_max_u(pk_add(acc.z, b.z), pk_add(acc.w, b.w)));
+    }
     for (int y = y0 + 1; y < y1; y++) {
         const uint4 a = *reinterpret_cast<const uint4 *>(hs + (int64_t)min(y + SH2, H - 1) * rowsz + e);
         const uint4 b = *reinterpret_cast<const uint4 *>(hs + (int64_t)max(y - SH2 - 1, 0) * rowsz + e);
-        acc.x = pk_sub(pk_add(acc.x, a.x), b.x); acc.y = pk_sub(pk_add(acc.y, a.y), b.y);
-        acc.z = pk_sub(pk_add(acc.z, a.z), b.z); acc.w = pk_sub(pk_add(acc.w, a.w), b.w);
+        const uint4 t = make_uint4(pk_add(acc.x, a.x), pk_add(acc.y, a.y), pk_add(acc.z, a.z), pk_add(acc.w, a.w));
+        hmax = pk_max_u(hmax, pk_max_u(pk_max_u(t.x, t.y), pk_max_u(t.z, t.w)));
+        acc.x = pk_sub(t.x, b.x); acc.y = pk_sub(t.y, b.y);
+        acc.z = pk_sub(t.z, b.z); acc.w = pk_sub(t.w, b.w);
         *reinterpret_cast<uint4 *>(C + (int64_t)y * rowsz + e) = acc;
     }
+    }
+    headroom_commit_pk(hr, 0, hmax);
 }
 
 // Same vertical box sum, each hsum row read ONCE: the last 2*SH2+2 rows of the column live in a
@@ -587,12 +609,14 @@ __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, in
 // by RS).  Instantiated for the common block sizes; other sizes use k_vsum.
 template <int SH2_, int NW /* dwords per thread: 2 or 4 */>
 __global__ __launch_bounds__(256) void k_vsum_ring(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
-                                                   int H, int64_t rowsz, int RB /* multiple of RS */, int band0)
+                                                   int H, int64_t rowsz, int RB /* multiple of RS */, int band0,
+                                                   uint32_t *hr)
 {
     constexpr int RS = SH2_ <= 1 ? 4 : (SH2_ <= 3 ? 8 : (SH2_ <= 7 ? 16 : 32));  // pow2 >= 2*SH2+2
     typedef Pack<NW> V;
     const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (2 * NW);  // 2*NW int16 per thread
-    if (e >= rowsz) return;
+    uint32_t hmax = 0;  // headroom record (packed running maximum)
+    if (e < rowsz) {
     const int y0 = (band0 + blockIdx.y) * RB, y1 = min(y0 + RB, H);
     V ring[RS];
     V acc;
@@ -605,7 +629,11 @@ __global__ __launch_bounds__(256) void k_vsum_ring(const int16_t *__restrict__ h
     auto step = [&](const V &v, int u, int y) {  // row y = yb + u enters its window's new bottom row v
         const V &o = ring[(u - SH2_ - 1) & (RS - 1)];
 #pragma unroll
-        for (int i = 0; i < NW; i++) acc.r[i] = pk_sub(pk_add(acc.r[i], v.r[i]), o.r[i]);
+        for (int i = 0; i < NW; i++) {
+            const uint32_t t = pk_add(acc.r[i], v.r[i]);  // C(y-1) + hsum(y+r): an int16 lane upstream
+            hmax = pk_max_u(hmax, t);
+            acc.r[i] = pk_sub(t, o.r[i]);
+        }
         ring[(u + SH2_) & (RS - 1)] = v;
         acc.store(C + (int64_t)y * rowsz + e);
     };
@@ -618,6 +646,13 @@ __global__ __launch_bounds__(256) void k_vsum_ring(const int16_t *__restrict__ h
         for (int i = 0; i < NW; i++) acc.r[i] = pk_add(acc.r[i], v.r[i]);
     }
     acc.store(C + (int64_t)y0 * rowsz + e);
+    {   // the first row of a band as upstream reaches it: C(y0-1) + hsum(y0+r) = C(y0) + hsum(y0-r-1)
+        V b;
+        b.fill(0);
+        if (y0 > 0) b = ld(y0 - SH2_ - 1);
+#pragma unroll
+        for (int i = 0; i < NW; i++) hmax = pk_max_u(hmax, pk_add(acc.r[i], b.r[i]));
+    }
     // a guarded block of RS rows (band edges, rows whose incoming tap is clamped)
     auto block_slow = [&](int yb) {
 #pragma unroll
@@ -655,6 +690,8 @@ __global__ __launch_bounds__(256) void k_vsum_ring(const int16_t *__restrict__ h
         yb += RS;
     }
     for (; yb < y1; yb += RS) block_slow(yb);
+    }
+    headroom_commit_pk(hr, 0, hmax);
 }
 
 }  // namespace sgm

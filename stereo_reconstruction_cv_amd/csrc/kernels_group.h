@@ -57,6 +57,7 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
     Pack<NP> L;
     L.fill(init);
     ShiftRegs sr;
+    uint32_t hm = 0;  // headroom record: largest min_d L_r(p, d) of this lane's row
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
     const int x0 = rx > 0 ? 0 : W1 - 1;
     auto load_t = [&](auto full_c, Pack<NP> *cb, Pack<NP> *sb, int k0) {
@@ -74,7 +75,9 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
         uint32_t rmin;
         path_elem<NP, PARTIAL, GW>(cv, L, P1s, P2s, active, Ln, rmin, sr, ge);
         const uint32_t m = group_min_pk<GW>(rmin);
-        path_normalise<NP, PARTIAL>(Ln, min(m & 0xffffu, m >> 16), active, Lnorm);
+        const uint32_t mL = min(m & 0xffffu, m >> 16);
+        hm = max(hm, mL);
+        path_normalise<NP, PARTIAL>(Ln, mL, active, Lnorm);
         Pack<NP> Sn;
 #pragma unroll
         for (int i = 0; i < NP; i++) Sn.r[i] = MODE == PATH_FIRST ? Ln.r[i] : pk_adds_s(sv.r[i], Ln.r[i]);
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
         load_t(part, cA, sA, k0 + 2 * PB);
         compute_t(part, cB, sB, k0 + PB);
     }
+    headroom_commit_pk(g.hr, 1, active ? hm : 0u);
 }
 
 // The four directions of a pass (in-row + the three from the previous row) for D <= 64, 64/GW rows
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(64) void k_rows4_g(Geom g, int xdir, int ydir, cons
     Pack<NP> L0;  // normalised state of the in-row path
     L0.fill(init);
     ShiftRegs sr0, srA, srB, srC;
+    uint32_t hm = 0;  // headroom record, in-row direction
     struct Px {
         Pack<NP> c, s, qa, qb, qc;
     };
@@ -198,7 +203,9 @@ __global__ __launch_bounds__(64) void k_rows4_g(Geom g, int xdir, int ydir, cons
         path_elem<NP, true, GW>(p.c, QB, P1s, P2s, active, NB, rB, srB, ge);
         path_elem<NP, true, GW>(p.c, QC, P1s, P2s, active, NC, rC, srC, ge);
         const uint32_t m = group_min_pk<GW>(r0);
-        path_normalise<NP, true>(N0, min(m & 0xffffu, m >> 16), active, Ln);
+        const uint32_t mL = min(m & 0xffffu, m >> 16);
+        hm = max(hm, mL);  // (the three other directions are recorded by k_prepass3_g)
+        path_normalise<NP, true>(N0, mL, active, Ln);
         L0 = Ln;
         Pack<NP> Sn;
         uint32_t v = pk_adds_s(pk_adds_s(N0.r[0], NA.r[0]), pk_adds_s(NB.r[0], NC.r[0]));
@@ -228,6 +235,7 @@ __global__ __launch_bounds__(64) void k_rows4_g(Geom g, int xdir, int ydir, cons
         load_t(part, pA, k0 + 2 * PB);
         compute_t(part, pB, k0 + PB);
     }
+    headroom_commit_pk(g.hr, 1, active ? hm : 0u);
 }
 
 // Boundary pre-pass for k_rows4_g (band height 1: the state after EVERY row is stored), 64/GW path
@@ -268,6 +276,7 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
 #pragma unroll
     for (int d = 0; d < 3; d++) L[d].fill(init);
     ShiftRegs sr[3];
+    uint32_t hm = 0;
     auto issue = [&](Pack<NP> *c3, int s) {  // C of sweep-order row s at the load cursors, then advance them
         const int rowoff = (y0 + s * ydir) * row_bytes;
 #pragma unroll
@@ -287,9 +296,11 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
         for (int d = 0; d < 3; d++) path_elem<NP, true, GW>(cv[u][d], L[d], P1s, P2s, active, N[d], r[d], sr[d], ge);
         uint32_t mm[2] = {pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])), r[2]};
         group_min_pk_n<GW, 2>(mm);
+        const uint32_t m2 = min(mm[1] & 0xffffu, mm[1] >> 16);
+        if (s < H) hm = max(hm, max(max(mm[0] & 0xffffu, mm[0] >> 16), m2));  // headroom record of the three directions
         path_normalise<NP, true>(N[0], mm[0] & 0xffffu, active, L[0]);
         path_normalise<NP, true>(N[1], mm[0] >> 16, active, L[1]);
-        path_normalise<NP, true>(N[2], min(mm[1] & 0xffffu, mm[1] >> 16), active, L[2]);
+        path_normalise<NP, true>(N[2], m2, active, L[2]);
         // the state the row s + 1 will read: bnd[s + 1][column][role][D]
 #pragma unroll
         for (int d = 0; d < 3; d++) {
@@ -308,6 +319,7 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
 #pragma unroll
     for (int u = 0; u < PF; u++)
         if (s0 + u < H) row(u, s0 + u);
+    headroom_commit_pk(g.hr, 1, active ? hm : 0u);
 }
 
 }  // namespace sgm

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
     L.fill(init);
     ShiftRegs sr;
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
+    uint32_t hm = 0;  // headroom record: largest min_d L_r(p, d) along this line
     int to_boundary = bd.R - 1, next_band = 1;  // PATH_BOUNDARY bookkeeping
 
     auto load_fast = [&](Pack<NP> *cb, Pack<NP> *sb) {
@@ -318,7 +319,9 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
         Pack<NP> Ln, Lnorm;
         uint32_t rmin;
         path_elem<NP, PARTIAL>(cv, L, P1s, P2s, active, Ln, rmin, sr);
-        path_normalise<NP, PARTIAL>(Ln, halves_min(wave_min_pk(rmin)), active, Lnorm);
+        const uint32_t mL = halves_min(wave_min_pk(rmin));
+        hm = max(hm, mL);
+        path_normalise<NP, PARTIAL>(Ln, mL, active, Lnorm);
         if (MODE == PATH_BOUNDARY) {
             // state of the last row of a band, consumed by the first row of the next band
             if (to_boundary == 0) {
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
             compute_slow(cB, sB, s0 + PB);
         }
     }
+    if (g.hr && lane == 0) atomicMax(g.hr + 1, hm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -486,6 +490,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
     };
 
     int to_boundary = R - 1, next_band = 1;
+    uint32_t hm_hi = 0, hm_lo = 0;
     auto one_step = [&](Pack<NP> *c3, bool store_ok) {
         Pack<NP> N[3];
         uint32_t r[3];
@@ -493,6 +498,8 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
         for (int d = 0; d < 3; d++) path_elem<NP, PARTIAL>(c3[d], L[d], P1s, P2s, active, N[d], r[d], sr[d]);
         const uint32_t m01 = wave_min_pk(pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])));
         const uint32_t m2 = halves_min(wave_min_pk(r[2]));
+        hm_hi = max(hm_hi, m01);  // headroom record (scalar; see k_sweep)
+        hm_lo = max(hm_lo, max(m01 & 0xffffu, m2));
         path_normalise<NP, PARTIAL>(N[0], m01 & 0xffffu, active, L[0]);
         path_normalise<NP, PARTIAL>(N[1], m01 >> 16, active, L[1]);
         path_normalise<NP, PARTIAL>(N[2], m2, active, L[2]);
@@ -551,6 +558,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
             compute_slow(cB, s0 + PB);
         }
     }
+    if (g.hr && lane == 0) atomicMax(g.hr + 1, max(hm_hi >> 16, hm_lo));
 }
 
 }  // namespace sgm

@@ -252,6 +252,11 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     Pack<NP> L0;  // normalised state of the in-row path
     L0.fill(init);
     ShiftRegs sr0, srA, srB, srC;
+    // headroom record (sgm_get_headroom): largest min_d L_r(p, d) of the row, all four directions.
+    // The reductions return {min of one direction, min of another} packed; an unsigned 32-bit
+    // maximum of such pairs keeps the largest HIGH half exactly, the low halves take their own
+    // maximum -- scalar instructions only, nothing added to the vector stream.
+    uint32_t hm_hi = 0, hm_lo = 0;
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
     // this row of C and S as buffer resources: one constant per-lane byte offset register plus a
     // scalar byte offset per pixel (b0 + k * bk), so no address VGPRs alias the load destinations
@@ -294,6 +299,8 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         path_elem<NP, PARTIAL>(Cp, QC, P1s, P2s, active, NC, rC, srC);
         const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));  // {min 0, min A}
         const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));  // {min B, min C}
+        hm_hi = max(hm_hi, max(m0A, mBC));
+        hm_lo = max(hm_lo, max(m0A & 0xffffu, mBC & 0xffffu));
         Pack<NP> LA, LB, LC;
         path_normalise<NP, PARTIAL>(N0, m0A & 0xffffu, active, L0);
         path_normalise<NP, PARTIAL>(NA, m0A >> 16, active, LA);
@@ -371,6 +378,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
             compute_block_t(part, cB, sB, k0 + PB);
         }
     }
+    if (g.hr && lane == 0) atomicMax(g.hr + 1, max(hm_hi >> 16, hm_lo));
     // one step after the last real pixel: the virtual pixel W1 (start state) for the row below
     if (wave < R - 1) {
         write_start_state(mine, W1 % RING);

@@ -51,6 +51,8 @@ __device__ __forceinline__ uint32_t from_upper_lane(uint32_t v, uint32_t fill)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, DPP_WAVE_SHL1, 0xf, 0xf, false);
 }
 
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 // One butterfly / broadcast step of a wave-wide reduction: y = x as seen through a DPP control.
 // mov_dpp (no "old" operand) lets the compiler emit a single v_mov_b32_dpp without a copy.
 template <int CTRL, int ROW_MASK = 0xf>
@@ -92,6 +94,26 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
+// max over the 64 lanes of an unsigned 32-bit value (headroom records: once per wave, at its end)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+    x = max(x, dpp_view<DPP_QUAD_1032>(x));
+    x = max(x, dpp_view<DPP_QUAD_2301>(x));
+    x = max(x, dpp_view<DPP_ROW_HALF_MIRROR>(x));
+    x = max(x, dpp_view<DPP_ROW_MIRROR>(x));
+    x = max(x, dpp_view<DPP_ROW_BCAST15, 0xa>(x));
+    x = max(x, dpp_view<DPP_ROW_BCAST31, 0xc>(x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+// Headroom record of one compute (sgm_get_headroom): hr[0] = max of C_true (incl. the running-sum
+// intermediate C(y-1) + hsum(y+r) upstream holds in an int16 lane), hr[1] = max over pixels and
+// directions of min_d L_r(p, d).  `v` holds per-lane packed uint16 maxima; one atomic per wave.
+__device__ __forceinline__ void headroom_commit_pk(uint32_t *hr, int slot, uint32_t v)
+{
+    const uint32_t m = wave_max_u32(max(v & 0xffffu, v >> 16));
+    if (hr && lane_id() == 0) atomicMax(hr + slot, m);
+}
+
 // N independent reductions with their DPP steps interleaved: a DPP read needs two wait states
 // after the VALU write of its source, which a second chain fills (a lone chain gets s_nop's).
 template <int N> __device__ __forceinline__ void wave_min_pk_n(uint32_t (&x)[N])
@@ -126,8 +148,6 @@ template <int N> __device__ __forceinline__ void wave_min_u32_n(uint32_t (&x)[N]
 // ---- lane groups (small D): a wave of 64 lanes holds 64/GW independent pixels of GW lanes each ----
 // Reductions that leave the group's result in EVERY lane of the group (a VGPR value that differs
 // between groups); GW = 64 is the wave-uniform case above.
-__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
 template <int GW, int N> __device__ __forceinline__ void group_min_pk_n(uint32_t (&x)[N])
 {
     if constexpr (GW == 64) {

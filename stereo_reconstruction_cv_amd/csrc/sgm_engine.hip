@@ -99,6 +99,7 @@ struct sgm_engine {
     DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
     DevBuf rmap1, rmap2, rsrc, rdst;    // host-pointer rectification stages
     DevBuf ccount, cpts, crgb, crgb_in; // point compaction
+    DevBuf headroom;                    // uint32[2]: max C_true (incl. upstream's running-sum intermediate), max min_d L_r
 
     // profiling
     std::vector<hipEvent_t> events;
@@ -135,6 +136,7 @@ static int normalise(const sgm_params *p, int H, int W, Geom *g)
     g->mode = p->mode;
     g->NP = g->D <= 128 ? 1 : (g->D <= 256 ? 2 : 4);
     g->rowsz = (int64_t)std::max(g->W1, 0) * g->D;
+    g->hr = nullptr;
     return SGM_OK;
 }
 
@@ -293,6 +295,8 @@ static int ensure_buffers(sgm_engine *e, int H, int W)
     if ((rc = e->wta.ensure(npx * 8))) return rc;
     if ((rc = e->disp_raw.ensure(npx * 2))) return rc;
     if ((rc = e->disp_med.ensure(npx * 2))) return rc;
+    if ((rc = e->headroom.ensure(8))) return rc;
+    e->g.hr = (uint32_t *)e->headroom.p;
     return SGM_OK;
 }
 
@@ -334,6 +338,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
     const unsigned nb_px = (unsigned)((npx + 255) / 256);
 
     int16_t *raw = (int16_t *)e->disp_raw.p, *med = (int16_t *)e->disp_med.p;
+    HIP_TRY(hipMemsetAsync(e->headroom.p, 0, 8, st));  // headroom record of this compute (sgm_get_headroom)
 
     if (g.W1 <= 0) {
         // no column can be matched: the whole map is invalid (upstream early-out), then median
@@ -402,8 +407,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             dim3 block(256), gridr((unsigned)((g.rowsz / per_thread + 255) / 256), nb);
 #define SGM_VSUM(SH2_)                                                                                             \
     case SH2_:                                                                                                     \
-        if (wide) hipLaunchKernelGGL((k_vsum_ring<SH2_, 4>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, band0); \
-        else hipLaunchKernelGGL((k_vsum_ring<SH2_, 2>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, band0);      \
+        if (wide) hipLaunchKernelGGL((k_vsum_ring<SH2_, 4>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, band0, g.hr); \
+        else hipLaunchKernelGGL((k_vsum_ring<SH2_, 2>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, band0, g.hr); \
         break;
             switch (g.SH2) {  // ring variant: each hsum row is read once
                 SGM_VSUM(1)
@@ -478,7 +483,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             launch_vsum(0, nvb);
         } else {
             dim3 block(256), grid((unsigned)((g.rowsz / 8 + 255) / 256), (H + 63) / 64);
-            hipLaunchKernelGGL(k_vsum, grid, block, 0, st, hsp, cp, H, g.rowsz, g.SH2, 64);
+            hipLaunchKernelGGL(k_vsum, grid, block, 0, st, hsp, cp, H, g.rowsz, g.SH2, 64, g.hr);
         }
         KCHECK();
         if ((rc = stage_end(e, 1))) return rc;
@@ -689,7 +694,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
     if ((rc = stage_begin(e, "speckle"))) return rc;
     int nl = 1;
     HIP_TRY(hipMemcpyAsync(d_disp, med, (size_t)npx * 2, hipMemcpyDeviceToDevice, st));
-    if (e->params.speckleWindowSize > 0) {
+    if (e->params.speckleRange >= 0 && e->params.speckleWindowSize > 0) {  // upstream's condition for filterSpeckles
         if ((rc = run_speckles(e, d_disp, H, W, (e->params.minDisparity - 1) * 16, e->params.speckleWindowSize,
                                16 * e->params.speckleRange)))
             return rc;
@@ -792,7 +797,7 @@ void sgm_destroy(sgm_engine *e)
     (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
-                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in};
+                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->aux) {
@@ -1213,6 +1218,22 @@ int sgm_get_tap(sgm_engine *e, int tap, void *host_dst, int64_t bytes)
     if (need == 0) return SGM_OK;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(host_dst, src, (size_t)need, hipMemcpyDeviceToHost));
+    return SGM_OK;
+}
+
+int sgm_get_headroom(sgm_engine *e, int *max_cost_plus_p2, int *max_delta, int *ok)
+{
+    if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
+    if (e->H <= 0 || !e->headroom.p) return set_err(SGM_ERR_INVALID_ARG, "no compute has run yet");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    uint32_t h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, e->headroom.p, 8, hipMemcpyDeviceToHost));
+    // an int16 lane upstream holds C_true + P2 and min_d L_r + P2: both must fit
+    const int64_t a = e->g.W1 > 0 ? (int64_t)h[0] + e->g.P2 : 0, b = e->g.W1 > 0 ? (int64_t)h[1] + e->g.P2 : 0;
+    if (max_cost_plus_p2) *max_cost_plus_p2 = (int)std::min<int64_t>(a, INT32_MAX);
+    if (max_delta) *max_delta = (int)std::min<int64_t>(b, INT32_MAX);
+    if (ok) *ok = (a <= SGM_MAX_COST && b <= SGM_MAX_COST) ? 1 : 0;
     return SGM_OK;
 }
 

@@ -95,6 +95,13 @@ class Engine:
         _check(self._L.sgm_get_stage_times(self._h, C.byref(st)))
         return [(st.name[i].decode(), float(st.ms[i]), int(st.launches[i])) for i in range(st.n)]
 
+    def headroom(self) -> dict:
+        """Regime record of the last compute (sgm_get_headroom): inside the int16 no-overflow regime
+        of OpenCV's StereoSGBM (where this engine's output is bit-exact) iff `ok`."""
+        a, b, ok = C.c_int(), C.c_int(), C.c_int()
+        _check(self._L.sgm_get_headroom(self._h, C.byref(a), C.byref(b), C.byref(ok)))
+        return dict(ok=bool(ok.value), max_cost_plus_p2=a.value, max_delta=b.value)
+
     def tap(self, which: int, H: int, W: int) -> np.ndarray:
         if which in (_lib.SGM_TAP_COST, _lib.SGM_TAP_AGGR):
             _, W1 = self.geometry(W)

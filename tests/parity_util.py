@@ -36,6 +36,7 @@ def run_hip_with_taps(left, right, p, schedule=1, sweep_rows=0, debug=0):
     if W1 > 0:
         out["C"] = eng.tap(_lib.SGM_TAP_COST, H, W)
         out["S"] = eng.tap(_lib.SGM_TAP_AGGR, H, W)
+    out["headroom"] = eng.headroom()     # the engine's own regime record (sgm_get_headroom)
     return out
 
 
@@ -48,10 +49,20 @@ def compare_stages(left, right, p, schedule=1, sweep_rows=0):
     for k in ("C", "S", "disp_raw", "disp_median", "disp"):
         if k in h and k in t:
             rep[k] = int((h[k] != t[k]).sum())
+    t["headroom"] = dict(ok=bool(t["headroom_ok"]), max_cost_plus_p2=t["max_cost_plus_p2"], max_delta=t["max_delta"])
+    rep["headroom"] = int(h["headroom"] != t["headroom"])
     return rep, t, h
 
 
+def headroom_equal(h, t) -> bool:
+    """device-side regime record == the oracle's (max C + P2 incl. the running-sum intermediate,
+    max min_d L_r + P2, and the verdict)"""
+    return h["headroom"] == dict(ok=bool(t["headroom_ok"]), max_cost_plus_p2=t["max_cost_plus_p2"], max_delta=t["max_delta"])
+
+
 def describe_mismatch(k, a, b):
+    if k == "headroom":
+        return f"headroom record: hip {a} != oracle {b}"
     idx = np.argwhere(a != b)
     s = f"{k}: {len(idx)} mismatches of {a.size}; first {idx[:5].tolist()}"
     if len(idx):

@@ -139,3 +139,14 @@ def test_headroom_flag():
     _, t = O.sgbm_compute(a, b, taps=True, numDisparities=16, blockSize=7, P1=10, P2=30000)
     # (the tracked maximum includes the running-sum intermediate C(y-1) + hsum(y+3) = 3087 + 441)
     assert t["max_cost_plus_p2"] == 3087 + 441 + 30000 and not t["headroom_ok"]
+
+
+def test_speckle_filter_needs_a_non_negative_range():
+    """upstream (StereoSGBMImpl::compute): filterSpeckles runs only if speckleRange >= 0 && speckleWindowSize > 0"""
+    l, r, _ = synth.make_pair(40, 160, 16, 12)
+    base = dict(numDisparities=16, blockSize=5, P1=200, P2=800, uniquenessRatio=10, disp12MaxDiff=1)
+    none = O.sgbm_compute(l, r, speckleWindowSize=0, speckleRange=2, **base)
+    neg = O.sgbm_compute(l, r, speckleWindowSize=100, speckleRange=-1, **base)
+    zero = O.sgbm_compute(l, r, speckleWindowSize=100, speckleRange=0, **base)
+    assert np.array_equal(neg, none)              # negative range: no filtering at all
+    assert (zero == -16).sum() > (none == -16).sum()   # range 0 filters (only equal neighbours link)
