@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--concurrent", type=int, default=0,
                     help="engines (HIP streams) working on different pairs at the same time; 0 = workload default")
     ap.add_argument("--schedule", type=int, default=1, help="0: one kernel per path direction, 1: fused sweeps")
+    ap.add_argument("--debug", type=int, default=0, help="SGM_OPT_DEBUG bit mask (A/B measurements; include/sgm_hip.h)")
+    ap.add_argument("--prepass-rows", type=int, default=0, help="rows per chunk of the boundary pre-pass (0 = automatic)")
     args = ap.parse_args()
 
     # ---- N > 1 without a launcher: become the parent of N ranks (before torch / HIP are imported)
@@ -270,6 +272,10 @@ def main():
         e = Engine(p, device=local_rank)
         e.set_option(OPT_PROFILE, 1)
         e.set_option(OPT_SCHEDULE, args.schedule)
+        if not mock and args.debug:
+            e.set_option(_lib.SGM_OPT_DEBUG, args.debug)
+        if not mock and args.prepass_rows:
+            e.set_option(_lib.SGM_OPT_PREPASS_ROWS, args.prepass_rows)
         engines.append(e)
     eng = engines[0]
 
@@ -425,6 +431,7 @@ def main():
                    "blockSize": bs, "mode": "MODE_HH" if mode else "MODE_SGBM", "pairs_per_gpu_per_step": ppg,
                    "global_pairs_per_step": ppg * world, "streams_per_gpu": nconc,
                    "schedule": "fused sweeps" if args.schedule else "one kernel per direction",
+                   **({"debug_mask": args.debug} if args.debug else {}),
                    "world_size": dist.get_world_size() if world > 1 else 1,
                    "frames_per_rank": [b - a for a, b in (sharding.shard_range(ppg * world, r, world) for r in range(world))],
                    "ingest": args.ingest,

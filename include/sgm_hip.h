@@ -85,13 +85,16 @@ typedef enum {
     SGM_OPT_PROFILE = 1,     /* 1: bracket every stage with HIP events on the engine's stream    */
     SGM_OPT_SCHEDULE = 2,    /* 0: one kernel per path direction; 1 (default): fused 4-direction sweeps */
     SGM_OPT_SWEEP_ROWS = 3,  /* rows per band of the fused sweep; 0 = automatic                  */
+    SGM_OPT_PREPASS_ROWS = 5, /* rows per chunk (= launch) of the boundary pre-pass; 0 = automatic (about 270) */
     SGM_OPT_DEBUG = 4        /* A/B switches for measurements, a bit mask.  Results stay correct except
                               * for bit 64.   2: winner-take-all fused into the last path kernel
                               * everywhere;  4: no lane groups for D <= 64;  8: narrow vertical box
                               * sum;  16: boundary pre-pass as three k_path launches;  32: no overlap of
                               * the upward pre-pass with the downward sweep;  64: the sweep's loader wave
                               * skips its HBM loads (timing only, results WRONG);  128: fork the upward
-                              * pre-pass right after the cost stage */
+                              * pre-pass right after the cost stage;  256: int16 cost pipeline (k_hsum +
+                              * k_vsum_ring) instead of the byte one;  512: boundary pre-pass in one chunk
+                              * with the plain line-per-block layout (no XCD grouping) */
 } sgm_option;
 
 #define SGM_MAX_STAGES 32

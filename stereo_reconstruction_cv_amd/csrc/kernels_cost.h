@@ -477,7 +477,8 @@ __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restric
 #pragma unroll
     for (int c = 0; c < XC; c++)
 #pragma unroll
-        for (int i = 0; i < NP; i++) hmax = pk_max_u(hmax, y0 > 0 ? pk_add(acc[c][i], hs[c][i]) : acc[c][i]);
+        for (int i = 0; i < NP; i++)
+            if (x0 + c < W1) hmax = pk_max_u(hmax, y0 > 0 ? pk_add(acc[c][i], hs[c][i]) : acc[c][i]);
     for (int yb = y0; yb < y1; yb += RS) {
 #pragma unroll
         for (int u = 0; u < RS; u++) {
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restric
 #pragma unroll
                     for (int i = 0; i < NP; i++) {
                         const uint32_t t = pk_add(acc[c][i], hs[c][i]);  // C(y-1) + hsum(y+R): an int16 lane upstream
-                        hmax = pk_max_u(hmax, t);
+                        if (x0 + c < W1) hmax = pk_max_u(hmax, t);       // (columns past W1 hold no real sums)
                         acc[c][i] = pk_sub(t, ring[(u - R - 1) & (RS - 1)][c][i]);
                         ring[(u + R) & (RS - 1)][c][i] = hs[c][i];
                     }

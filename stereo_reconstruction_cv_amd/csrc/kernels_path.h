@@ -390,24 +390,44 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
 }
 
 // ------------------------------------------------------------------------------------------
-// Boundary pre-pass for k_sweep, all three roles in one wave: line `blockIdx.x` of each of the
-// directions (rx = +xdir, 0, -xdir; ry = ydir) is advanced together, one image row per step.
-// Three independent dependency chains per wave (the scheduler interleaves them).  Only the
-// normalised state at band boundaries is stored (Boundary layout above).
+// Boundary pre-pass for k_sweep, all three roles in one wave: one line of each of the directions
+// (rx = +xdir, 0, -xdir; ry = ydir) is advanced together, one image row per step.  Three
+// independent dependency chains per wave (the scheduler interleaves them).  Only the normalised
+// state at band boundaries is stored (Boundary layout above).
+//
+// C traffic.  A pixel of C is needed by three lines (one per role).  With a fixed line per wave the
+// three readers of a pixel drift apart as the diagonals move (they sit on different XCDs, whose L2s
+// share nothing): C was fetched three times per pass.  Now the image is walked in CHUNKS of rows
+// (one launch per chunk, steps [s_begin, s_end)), and within a chunk a wave follows the three
+// lines that cross ITS base column b in the middle of the chunk.  Workgroups are dealt to the
+// XCDs round-robin (MI355X_MICROARCH.md: blocks b and b + 8 share an XCD -- observed, not a
+// contract; it only decides speed), so base columns are laid out per XCD group: group i of
+// blockIdx % 8 owns columns [i*cpx, (i+1)*cpx).  The three roles of a group then read the same
+// C rows within +-chunk/2 columns of each other at about the same time: two of the three reads hit
+// the group's L2.  Between chunks the state of every line goes through a small ping-pong buffer
+// indexed by (role, column at the chunk border): state_in / state_out, [3][W1][D] int16 each.
 //
 // Prefetch discipline (see kernels_sweep.h): the cost volume is one buffer resource, every load
 // is "constant per-lane offset register + scalar byte offset", and an iteration of two blocks
 // in which no diagonal leaves the image is straight-line code, so hipcc keeps the next block's
 // loads in flight (counted vmcnt).  The rare iterations with a wrap take the per-step path.
-// Byte offsets are 32-bit (the host checks volume bytes < 2^32).
+// Byte offsets are 32-bit (the host checks volume bytes < 2^31).
 template <int NP, bool PARTIAL>
 __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
-                                                 int16_t *__restrict__ bndL, int R)
+                                                 int16_t *__restrict__ bndL, int R, int s_begin, int s_end,
+                                                 const int16_t *__restrict__ state_in, int16_t *__restrict__ state_out,
+                                                 int cpx)
 {
     constexpr int PB = 4;  // rows per prefetch block: 2 blocks x 3 roles in registers keeps 4 waves per SIMD
     const int lane = threadIdx.x;
-    const int line = blockIdx.x;
     const int W1 = g.W1, D = g.D, H = g.H;
+    // base column of this wave: XCD-group layout (cpx > 0) or the plain one
+    int base = blockIdx.x;
+    if (cpx > 0) {
+        const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        base = grp * cpx + slot;
+        if (slot >= cpx || base >= W1) return;
+    }
     const bool active = !PARTIAL || (2 * NP * lane < D);
     const int lane_off = active ? 2 * NP * lane : 0;
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
@@ -421,18 +441,22 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
 #pragma unroll
     for (int d = 0; d < 3; d++) stride[d] = (uint32_t)(ydir * (int)row_bytes + rx[d] * D * 2);
 
-    // per role: column of the next pixel of the load / compute cursors, byte offset of the load cursor
+    // per role: column of the next pixel of the load / compute cursors, byte offset of the load cursor.
+    // The line of role d stands at column base in the middle row of the chunk.
     int xl[3], xc[3];
     uint32_t offl[3];
-    const int y0 = ydir > 0 ? 0 : H - 1;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        xl[d] = xc[d] = line;
-        offl[d] = ((uint32_t)y0 * W1 + line) * D * 2;
-    }
+    const int y_begin = ydir > 0 ? s_begin : H - 1 - s_begin;
+    const int back = (s_begin + s_end) / 2 - s_begin;  // steps from the chunk's first row to its middle
     Pack<NP> L[3];
 #pragma unroll
-    for (int d = 0; d < 3; d++) L[d].fill(init);
+    for (int d = 0; d < 3; d++) {
+        int x = (base - rx[d] * back) % W1;  // |rx * back| may exceed W1 on narrow frames
+        if (x < 0) x += W1;
+        xl[d] = xc[d] = x;
+        offl[d] = ((uint32_t)y_begin * W1 + x) * D * 2;
+        L[d].fill(init);
+        if (s_begin > 0 && active) L[d].load(state_in + ((int64_t)d * W1 + x) * D + lane_off);
+    }
     ShiftRegs sr[3];
     Pack<NP> cA[PB][3], cB[PB][3];
 
@@ -477,7 +501,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
     auto load_slow = [&](Pack<NP>(*cb)[3], int step0) {
 #pragma unroll
         for (int k = 0; k < PB; k++) {
-            if (step0 + k < H) {
+            if (step0 + k < s_end) {
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
                     buf_load<NP>(cb[k][d], Cbuf, voff, (int)offl[d]);
@@ -489,7 +513,8 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
         }
     };
 
-    int to_boundary = R - 1, next_band = 1;
+    // rows s with (s + 1) % R == 0 end a band: their state goes to the record of band (s + 1) / R
+    int to_boundary = R - 1 - s_begin % R, next_band = s_begin / R + 1;
     uint32_t hm_hi = 0, hm_lo = 0;
     auto one_step = [&](Pack<NP> *c3, bool store_ok) {
         Pack<NP> N[3];
@@ -525,7 +550,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
     auto compute_slow = [&](Pack<NP>(*cb)[3], int step0) {
 #pragma unroll
         for (int k = 0; k < PB; k++) {
-            if (step0 + k < H) {
+            if (step0 + k < s_end) {
                 one_step(cb[k], step0 + k + 1 < H);
 #pragma unroll
                 for (int d = 0; d < 3; d++) xc[d] += rx[d];
@@ -535,14 +560,14 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
     };
 
     // block s0 is in cA (loaded here); each iteration loads s0+PB -> cB and s0+2PB -> cA
-    if (PB <= H && stays(xl[0], 0, PB) && stays(xl[2], 2, PB)) {
+    if (s_begin + PB <= s_end && stays(xl[0], 0, PB) && stays(xl[2], 2, PB)) {
         load_fast(cA);
         wrap_load();
     } else {
-        load_slow(cA, 0);
+        load_slow(cA, s_begin);
     }
-    for (int s0 = 0; s0 < H; s0 += 2 * PB) {
-        const bool fast = s0 + 3 * PB <= H && stays(xl[0], 0, 2 * PB) && stays(xl[2], 2, 2 * PB) &&
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * PB) {
+        const bool fast = s0 + 3 * PB <= s_end && stays(xl[0], 0, 2 * PB) && stays(xl[2], 2, 2 * PB) &&
                           stays(xc[0], 0, 2 * PB) && stays(xc[2], 2, 2 * PB);
         if (fast) {
             load_fast(cB);
@@ -557,6 +582,11 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
             load_slow(cA, s0 + 2 * PB);
             compute_slow(cB, s0 + PB);
         }
+    }
+    // hand the three lines to whichever waves pick them up in the next chunk
+    if (s_end < H && active) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) L[d].store(state_out + ((int64_t)d * W1 + xc[d]) * D + lane_off);
     }
     if (g.hr && lane == 0) atomicMax(g.hr + 1, max(hm_hi >> 16, hm_lo));
 }

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -83,6 +85,7 @@ struct sgm_engine {
     int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps
     int sweep_rows = 0;  // rows per band of the sweep (0 = automatic)
     int debug = 0;       // timing experiments (SweepArgs::dbg)
+    int prepass_rows = 0;  // rows per chunk of the boundary pre-pass (0 = automatic, about 270)
     sgm_engine *peer = nullptr;  // second engine (own stream and buffers) for two pairs in flight in sgm_compute_batch
 
     // shape of the last compute
@@ -94,6 +97,7 @@ struct sgm_engine {
     DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
     DevBuf wta;                         // uint2 [H][W]
     DevBuf bndL, bndL2;                 // band-boundary state of the sweep pre-pass (down / up)
+    DevBuf pstate, pstate2;             // line state between the row chunks of the pre-pass (ping-pong, down / up)
     DevBuf disp_raw, disp_med, disp_out;  // int16 [H][W]
     DevBuf label, csize, rlen;          // int32 [H][W] each
     DevBuf f32, xyz, mask, minkey;      // host-pointer post stages
@@ -105,6 +109,7 @@ struct sgm_engine {
     std::vector<hipEvent_t> events;
     std::vector<const char *> stage_names;
     std::vector<int> stage_launches;
+    uint64_t stage_range[SGM_MAX_STAGES] = {};  // roctx range ids of the open stages
     int nstages = 0;
 };
 
@@ -141,10 +146,36 @@ static int normalise(const sgm_params *p, int H, int W, Geom *g)
 }
 
 // ---- stage bookkeeping -----------------------------------------------------------------------
+// roctx ranges around every stage while SGM_OPT_PROFILE is on (named ranges in rocprofv3
+// --marker-trace timelines; they bracket the host-side enqueue of the stage).  The tracing library
+// is looked up at run time: no link-time dependency, silently absent when it is not installed.
+struct Roctx {
+    uint64_t (*start)(const char *) = nullptr;
+    void (*stop)(uint64_t) = nullptr;
+    Roctx()
+    {
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_LOCAL)) {
+                start = (uint64_t(*)(const char *))dlsym(h, "roctxRangeStartA");
+                stop = (void (*)(uint64_t))dlsym(h, "roctxRangeStop");
+                if (start && stop) return;
+                start = nullptr;
+                stop = nullptr;
+            }
+        }
+    }
+};
+static Roctx &roctx()
+{
+    static Roctx r;
+    return r;
+}
+
 static int stage_begin(sgm_engine *e, const char *name, hipStream_t on = nullptr)
 {
     if (!e->profile) return SGM_OK;
     if (e->nstages >= SGM_MAX_STAGES) return SGM_OK;
+    if (roctx().start) e->stage_range[e->nstages] = roctx().start(name);
     const size_t need = (size_t)(e->nstages + 1) * 2;
     while (e->events.size() < need) {
         hipEvent_t ev;
@@ -164,6 +195,7 @@ static int stage_end(sgm_engine *e, int launches, hipStream_t on = nullptr)
     if (e->nstages >= SGM_MAX_STAGES) return SGM_OK;
     e->stage_launches[e->nstages] = launches;
     HIP_TRY(hipEventRecord(e->events[e->nstages * 2 + 1], on ? on : e->stream));
+    if (roctx().stop) roctx().stop(e->stage_range[e->nstages]);
     e->nstages++;
     return SGM_OK;
 }
@@ -532,35 +564,49 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             if (nbands > 1) {
                 if ((rc = e->bndL.ensure(bnd_bytes))) return rc;
                 if (npass == 2 && (rc = e->bndL2.ensure(bnd_bytes))) return rc;
+                const size_t st_bytes = (size_t)2 * 3 * g.W1 * g.D * 2;  // ping-pong line state between pre-pass chunks
+                if ((rc = e->pstate.ensure(st_bytes))) return rc;
+                if (npass == 2 && (rc = e->pstate2.ensure(st_bytes))) return rc;
             }
             // roles of the pre-pass: 0 = predecessor one step earlier in the sweep's x order
             // (x - xdir), 1 = same column, 2 = one step later
-            auto launch_prepass = [&](int xdir, int ydir, int16_t *bl, hipStream_t on) {
+            auto launch_prepass = [&](int xdir, int ydir, int16_t *bl, hipStream_t on) -> int {  // returns the launch count
                 if (rows4 && !(e->debug & 16)) {  // lane-grouped lines, state stored after every row
                     dim3 grid((g.W1 + 64 / GWs - 1) / (64 / GWs)), block(64);
                     if (GWs == 8) hipLaunchKernelGGL(k_prepass3_g<8>, grid, block, 0, on, g, xdir, ydir, C, bl);
                     else hipLaunchKernelGGL(k_prepass3_g<16>, grid, block, 0, on, g, xdir, ydir, C, bl);
-                    return;
+                    return 1;
                 }
                 if (!(e->debug & 16) && (int64_t)g.rowsz * H < (1ll << 31)) {
-                    // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant
+                    // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant.
+                    // Row chunks of about 270 rows, one launch each, base columns grouped per XCD: two of the
+                    // three reads of a C pixel hit L2 (kernels_path.h).  debug 512: one chunk, plain layout (A/B).
                     const bool partial = g.D != 128 * g.NP;
-                    dim3 grid(g.W1), block(64);
-                    if (g.NP == 1) {
-                        if (partial) hipLaunchKernelGGL((k_prepass3<1, true>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
-                        else hipLaunchKernelGGL((k_prepass3<1, false>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
-                    } else if (g.NP == 2) {
-                        if (partial) hipLaunchKernelGGL((k_prepass3<2, true>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
-                        else hipLaunchKernelGGL((k_prepass3<2, false>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
-                    } else {
-                        if (partial) hipLaunchKernelGGL((k_prepass3<4, true>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
-                        else hipLaunchKernelGGL((k_prepass3<4, false>), grid, block, 0, on, g, xdir, ydir, C, bl, R);
+                    const bool plain = (e->debug & 512) != 0;
+                    const int nch = plain ? 1 : (e->prepass_rows > 0 ? (H + e->prepass_rows - 1) / e->prepass_rows
+                                                                          : std::max(1, (H + 135) / 270));
+                    const int Hc = (H + nch - 1) / nch;
+                    const int cpx = plain ? 0 : (g.W1 + 7) / 8;
+                    dim3 grid(plain ? g.W1 : 8 * cpx), block(64);
+                    const size_t half = (size_t)3 * g.W1 * g.D;  // int16 elements of one state buffer
+                    int16_t *sbuf = (int16_t *)(ydir > 0 ? e->pstate.p : e->pstate2.p);
+                    for (int c = 0; c < nch; c++) {
+                        const int s0 = c * Hc, s1 = std::min(H, s0 + Hc);
+                        if (s0 >= s1) break;
+                        const int16_t *sin = sbuf ? sbuf + (size_t)(c & 1) * half : nullptr;
+                        int16_t *sout = sbuf ? sbuf + (size_t)((c + 1) & 1) * half : nullptr;
+#define SGM_PRE(NP_, PART_) hipLaunchKernelGGL((k_prepass3<NP_, PART_>), grid, block, 0, on, g, xdir, ydir, C, bl, R, s0, s1, sin, sout, cpx)
+                        if (g.NP == 1) { if (partial) SGM_PRE(1, true); else SGM_PRE(1, false); }
+                        else if (g.NP == 2) { if (partial) SGM_PRE(2, true); else SGM_PRE(2, false); }
+                        else { if (partial) SGM_PRE(4, true); else SGM_PRE(4, false); }
+#undef SGM_PRE
                     }
-                } else {
-                    // one launch of the single-direction kernel, grid.y = role
-                    Boundary bd{bl, R, 0};
-                    launch_path(g, xdir, ydir, PATH_BOUNDARY, C, S, 0, wta, on, bd);
+                    return nch;
                 }
+                // one launch of the single-direction kernel, grid.y = role
+                Boundary bd{bl, R, 0};
+                launch_path(g, xdir, ydir, PATH_BOUNDARY, C, S, 0, wta, on, bd);
+                return 1;
             };
             // MODE_HH: the upward pre-pass only reads C, so it runs on the auxiliary stream while the
             // main stream does the downward pre-pass and sweep (memory-bound beside issue-bound work)
@@ -575,9 +621,9 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 HIP_TRY(hipEventRecord(e->ev_fork, st));
                 HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
                 if ((rc2 = stage_begin(e, "prepass_up", e->aux))) return rc2;
-                launch_prepass(-1, -1, (int16_t *)e->bndL2.p, e->aux);
+                const int nl = launch_prepass(-1, -1, (int16_t *)e->bndL2.p, e->aux);
                 KCHECK();
-                if ((rc2 = stage_end(e, 1, e->aux))) return rc2;
+                if ((rc2 = stage_end(e, nl, e->aux))) return rc2;
                 HIP_TRY(hipEventRecord(e->ev_join, e->aux));
                 return SGM_OK;
             };
@@ -595,9 +641,9 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 int16_t *bl = (int16_t *)(pass == 0 ? e->bndL.p : e->bndL2.p);
                 if (nbands > 1 && !(overlap && pass == 1)) {
                     if ((rc = stage_begin(e, pass == 0 ? "prepass_dn" : "prepass_up"))) return rc;
-                    launch_prepass(xdir, ydir, bl, st);
+                    const int nl = launch_prepass(xdir, ydir, bl, st);
                     KCHECK();
-                    if ((rc = stage_end(e, 1))) return rc;
+                    if ((rc = stage_end(e, nl))) return rc;
                 }
                 if (overlap && pass == 0 && !fork_early && (rc = fork_prepass_up())) return rc;
                 if (overlap && pass == 1) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
@@ -795,7 +841,7 @@ void sgm_destroy(sgm_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2,
+    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2, &e->pstate, &e->pstate2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
                       &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom};
     for (DevBuf *b : bufs) b->release();
@@ -819,6 +865,7 @@ int sgm_set_option(sgm_engine *e, int option, int value)
     else if (option == SGM_OPT_SCHEDULE) e->schedule = value ? 1 : 0;
     else if (option == SGM_OPT_SWEEP_ROWS) e->sweep_rows = std::max(0, value);
     else if (option == SGM_OPT_DEBUG) e->debug = value;
+    else if (option == SGM_OPT_PREPASS_ROWS) e->prepass_rows = std::max(0, value);
     else return set_err(SGM_ERR_INVALID_ARG, "unknown option %d", option);
     return SGM_OK;
 }
@@ -1049,6 +1096,7 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
         q->schedule = e->schedule;
         q->sweep_rows = e->sweep_rows;
         q->debug = e->debug;
+        q->prepass_rows = e->prepass_rows;
         if ((rc = q->in_left.ensure(npx)) || (rc = q->in_right.ensure(npx)) || (rc = q->disp_out.ensure(npx * 2))) return rc;
         if (xyz_out && ((rc = q->f32.ensure(npx * 4)) || (rc = q->xyz.ensure(npx * 12)))) return rc;
     }

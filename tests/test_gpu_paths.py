@@ -32,7 +32,7 @@ def test_large_blocks_and_high_prefilter_caps(H, W, D, bs, cap, mode):
         assert not bad, f"schedule {schedule}: " + "\n".join(bad)
 
 
-@pytest.mark.parametrize("debug", [8, 16, 32, 128, 16 | 32, 4, 4 | 16])
+@pytest.mark.parametrize("debug", [8, 16, 32, 128, 16 | 32, 4, 4 | 16, 512])
 @pytest.mark.parametrize("H,W,D,bs,mode", [(45, 420, 256, 7, 1), (38, 300, 64, 5, 1), (41, 200, 16, 11, 0), (29, 640, 160, 5, 0)])
 def test_debug_switches_keep_results(debug, H, W, D, bs, mode):
     """8: k_vsum_ring with 4 int16 per thread; 16: the pre-pass as three launches of the single-direction
@@ -49,6 +49,24 @@ def test_debug_switches_keep_results(debug, H, W, D, bs, mode):
             assert np.array_equal(h[k], t[k]), (dbg, k)
         assert np.array_equal(h["disp"], want), dbg
         assert U.headroom_equal(h, t), (dbg, h["headroom"], t["max_cost_plus_p2"], t["max_delta"])
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 5, 7, 16, 64])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_prepass_row_chunks(chunk, mode):
+    """The boundary pre-pass walks the image in row chunks (one launch each) and hands the state of
+    every line from chunk to chunk through a ping-pong buffer, with the lines re-dealt to the waves
+    at every chunk (XCD-grouped base columns, kernels_path.h).  Chunk height must not matter --
+    also when diagonals wrap around the side border inside or exactly at the end of a chunk
+    (frames narrower than they are tall)."""
+    for (H, W, D, bs, rows, seed) in ((61, 300, 64, 5, 3, 71), (47, 420, 256, 7, 2, 72), (90, 120, 48, 3, 4, 73),
+                                      (33, 1100, 512, 3, 1, 74), (130, 100, 32, 5, 9, 75)):
+        l, r, _ = synth.make_pair(H, W, D, seed)
+        p = U.params(D, bs, 0, mode, speckleWindowSize=30, speckleRange=2)
+        rep, t, h = U.compare_stages(l, r, p, schedule=1, sweep_rows=rows, prepass_rows=chunk)
+        assert t["headroom_ok"]
+        bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
+        assert not bad, f"chunk={chunk} {(H, W, D)}: " + "\n".join(bad)
 
 
 def test_headroom_record_at_the_edge_of_the_regime():
