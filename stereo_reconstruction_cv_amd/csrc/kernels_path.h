@@ -211,6 +211,10 @@ __device__ __forceinline__ void wta_pixel(const Pack<NP> &Sn, int lane, bool act
     wta_pixels<NP, PARTIAL, POSW, 1>(S1, lane, active, D, uniq, r1);
 }
 
+#ifndef SGM_PREPASS_PB
+#define SGM_PREPASS_PB 4
+#endif
+
 struct Cursor {
     int xi, y;
 };
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
                                                  const int16_t *__restrict__ state_in, int16_t *__restrict__ state_out,
                                                  int cpx)
 {
-    constexpr int PB = 4;  // rows per prefetch block: 2 blocks x 3 roles in registers keeps 4 waves per SIMD
+    constexpr int PB = SGM_PREPASS_PB;  // rows per prefetch block: 2 blocks x 3 roles in registers keeps 4 waves per SIMD
     const int lane = threadIdx.x;
     const int W1 = g.W1, D = g.D, H = g.H;
     // base column of this wave: XCD-group layout (cpx > 0) or the plain one

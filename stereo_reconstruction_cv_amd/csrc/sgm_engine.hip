@@ -587,6 +587,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                                                                           : std::max(1, (H + 135) / 270));
                     const int Hc = (H + nch - 1) / nch;
                     const int cpx = plain ? 0 : (g.W1 + 7) / 8;
+                    // (Padding the grid so that every SIMD holds the same number of waves, and halving the
+                    // prefetch depth, were both measured: no change -- DESIGN.md 4.4.)
                     dim3 grid(plain ? g.W1 : 8 * cpx), block(64);
                     const size_t half = (size_t)3 * g.W1 * g.D;  // int16 elements of one state buffer
                     int16_t *sbuf = (int16_t *)(ydir > 0 ? e->pstate.p : e->pstate2.p);
