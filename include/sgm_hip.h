@@ -94,7 +94,8 @@ typedef enum {
                               * skips its HBM loads (timing only, results WRONG);  128: fork the upward
                               * pre-pass right after the cost stage;  256: int16 cost pipeline (k_hsum +
                               * k_vsum_ring) instead of the byte one;  512: boundary pre-pass in one chunk
-                              * with the plain line-per-block layout (no XCD grouping) */
+                              * with the plain line-per-block layout (no XCD grouping);  2048: winner-take-all
+                              * always as its own pass */
 } sgm_option;
 
 #define SGM_MAX_STAGES 32

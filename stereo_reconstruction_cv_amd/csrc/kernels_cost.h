@@ -33,14 +33,19 @@ struct Geom {
 };
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_features(const uint8_t *__restrict__ img, int64_t stride,
-                                                  int H, int W, int ftzero,
-                                                  uint2 *__restrict__ left_rec,
-                                                  uint8_t *__restrict__ right_planes)
+// blockIdx.z = 0: left image -> left_rec; 1: right image -> right_planes (one launch for the pair)
+__global__ __launch_bounds__(256) void k_features(const uint8_t *__restrict__ imgL, const uint8_t *__restrict__ imgR,
+                                                  int64_t stride, int H, int W, int ftzero,
+                                                  uint2 *__restrict__ left_rec_,
+                                                  uint8_t *__restrict__ right_planes_)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
+    const bool is_right = blockIdx.z != 0;
+    const uint8_t *img = is_right ? imgR : imgL;
+    uint2 *left_rec = is_right ? nullptr : left_rec_;
+    uint8_t *right_planes = is_right ? right_planes_ : nullptr;
     const uint8_t *row = img + (int64_t)y * stride;
     const uint8_t *up = y > 0 ? row - stride : row;
     const uint8_t *dn = y < H - 1 ? row + stride : row;

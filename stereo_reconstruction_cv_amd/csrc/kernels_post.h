@@ -197,8 +197,10 @@ __device__ __forceinline__ void cswap(int &a, int &b)
     b = hi;
 }
 
+// dst2 (nullable): a second copy of the result -- the engine's output buffer, on which the speckle
+// filter then works in place, while dst stays readable as the "after median" tap
 __global__ __launch_bounds__(256) void k_median3(const int16_t *__restrict__ src,
-                                                 int16_t *__restrict__ dst, int H, int W)
+                                                 int16_t *__restrict__ dst, int16_t *__restrict__ dst2, int H, int W)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(256) void k_median3(const int16_t *__restrict__ src
     cswap(p3, p6); cswap(p1, p4); cswap(p2, p5); cswap(p4, p7); cswap(p4, p2); cswap(p6, p4);
     cswap(p4, p2);
     dst[(int64_t)y * W + x] = (int16_t)p4;
+    if (dst2) dst2[(int64_t)y * W + x] = (int16_t)p4;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -388,13 +391,10 @@ struct QMat {
 // Appendix B: homogeneous point in double, sums in index order from 0, one rounding to float,
 // divide as multiply by the reciprocal, one more rounding.  The library is built with
 // -ffp-contract=off so that no fused multiply-add changes the double arithmetic.
-__global__ __launch_bounds__(256) void k_reproject(const float *__restrict__ disp, int H, int W, QMat Q,
-                                                   const uint32_t *minkey, float *__restrict__ xyz)
+__device__ __forceinline__ void reproject_px(float fd, int x, int y, int64_t i, const QMat &Q, const uint32_t *minkey,
+                                             float *__restrict__ xyz)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    const int64_t i = (int64_t)y * W + x;
-    const double d = (double)disp[i];
+    const double d = (double)fd;
     const double v[4] = {(double)x, (double)y, d, 1.0};
     double h[4];
 #pragma unroll
@@ -418,6 +418,29 @@ __global__ __launch_bounds__(256) void k_reproject(const float *__restrict__ dis
     xyz[i * 3 + 0] = o[0];
     xyz[i * 3 + 1] = o[1];
     xyz[i * 3 + 2] = o[2];
+}
+
+__global__ __launch_bounds__(256) void k_reproject(const float *__restrict__ disp, int H, int W, QMat Q,
+                                                   const uint32_t *minkey, float *__restrict__ xyz)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int64_t i = (int64_t)y * W + x;
+    reproject_px(disp[i], x, y, i, Q, minkey, xyz);
+}
+
+// The driver cell in one launch (main.ipynb:668-670 then :697): int16 disparity -> float disparity
+// (stored if dispf is non-null) -> XYZ.  Same arithmetic as k_disp_to_float followed by k_reproject.
+__global__ __launch_bounds__(256) void k_float_xyz(const int16_t *__restrict__ d16, int H, int W, QMat Q,
+                                                   float *__restrict__ dispf, float *__restrict__ xyz)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int64_t i = (int64_t)y * W + x;
+    const float f0 = (float)d16[i] / 16.0f;
+    const float f = f0 * (f0 > 0.0f ? 1.0f : 0.0f);
+    if (dispf) dispf[i] = f;
+    reproject_px(f, x, y, i, Q, nullptr, xyz);
 }
 
 // main.ipynb:726-730

@@ -388,12 +388,12 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // -- features
         if ((rc = stage_begin(e, "features"))) return rc;
         {
-            dim3 grid((W + 255) / 256, H), block(256);
-            hipLaunchKernelGGL(k_features, grid, block, 0, st, d_left, stride, H, W, g.ftzero, (uint2 *)e->lrec.p, (uint8_t *)nullptr);
-            hipLaunchKernelGGL(k_features, grid, block, 0, st, d_right, stride, H, W, g.ftzero, (uint2 *)nullptr, (uint8_t *)e->rplanes.p);
+            dim3 grid((W + 255) / 256, H, 2), block(256);
+            hipLaunchKernelGGL(k_features, grid, block, 0, st, d_left, d_right, stride, H, W, g.ftzero, (uint2 *)e->lrec.p,
+                               (uint8_t *)e->rplanes.p);
             KCHECK();
         }
-        if ((rc = stage_end(e, 2))) return rc;
+        if ((rc = stage_end(e, 1))) return rc;
 
         // -- horizontal box sum of the pixel cost
         // -- horizontal box sum of the pixel cost (rows y0 .. y1-1), vertical box sum -> block cost
@@ -632,11 +632,13 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // debug bit 64+128: fork right after the cost stage (both pre-passes side by side) instead
             // of after the downward pre-pass (upward pre-pass beside the downward sweep)
             const bool fork_early = (e->debug & 128) != 0;
-            // Winner-take-all: a separate pass over S (k_wta_t) after the second sweep of MODE_HH and
-            // after the lane-grouped in-row path of small D; fused into the in-row path kernel for
-            // MODE_SGBM with D > 64 (that kernel is latency-bound per row, the WTA rides along).
-            // debug 2 forces the fused form everywhere (A/B, cross-check).
-            const bool fused_wta = ((e->debug & 2) != 0 && !rows4) || (g.mode == 0 && ((e->debug & 4) || group_width(g, H) == 64));
+            // Winner-take-all: a separate pass over S (k_wta_t, one lane per pixel) after the second sweep
+            // of MODE_HH and after the in-row path of MODE_SGBM for D <= 128; fused into the in-row path
+            // kernel for MODE_SGBM with D > 128 (there the separate form costs a third volume of traffic:
+            // 4K D=256 2.49 ms fused against 2.56 + 0.73; D=128: 2.01 against 1.42 + 0.43, 1080p 0.79 against
+            // 0.44 + 0.10).  debug 2 forces the fused form everywhere, debug 2048 the separate one (A/B, cross-check).
+            const bool fused_wta = !(e->debug & 2048) && (((e->debug & 2) != 0 && !rows4) ||
+                                                          (g.mode == 0 && ((e->debug & 4) || g.D > 128)));
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
@@ -733,22 +735,20 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
     if ((rc = stage_begin(e, "median3"))) return rc;
     {
         dim3 grid((W + 255) / 256, H), block(256);
-        hipLaunchKernelGGL(k_median3, grid, block, 0, st, (const int16_t *)raw, med, H, W);
+        // the result goes to the median tap AND to the output buffer (the speckle filter works in place there)
+        hipLaunchKernelGGL(k_median3, grid, block, 0, st, (const int16_t *)raw, med, d_disp, H, W);
         KCHECK();
     }
     if ((rc = stage_end(e, 1))) return rc;
 
-    // -- speckle filter -> output
-    if ((rc = stage_begin(e, "speckle"))) return rc;
-    int nl = 1;
-    HIP_TRY(hipMemcpyAsync(d_disp, med, (size_t)npx * 2, hipMemcpyDeviceToDevice, st));
+    // -- speckle filter on the output
     if (e->params.speckleRange >= 0 && e->params.speckleWindowSize > 0) {  // upstream's condition for filterSpeckles
+        if ((rc = stage_begin(e, "speckle"))) return rc;
         if ((rc = run_speckles(e, d_disp, H, W, (e->params.minDisparity - 1) * 16, e->params.speckleWindowSize,
                                16 * e->params.speckleRange)))
             return rc;
-        nl = 5;
+        if ((rc = stage_end(e, 4))) return rc;
     }
-    if ((rc = stage_end(e, nl))) return rc;
     return SGM_OK;
 }
 
@@ -1041,19 +1041,21 @@ int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, 
     }
     if ((rc = run_compute(e, (const uint8_t *)d_left, (const uint8_t *)d_right, H, W, stride_bytes, di))) return rc;
     if (!d_disp_f32 && !d_xyz_f32) return SGM_OK;
-    float *df = (float *)d_disp_f32;
-    if (!df) {
-        if ((rc = e->f32.ensure((size_t)n * 4))) return rc;
-        df = (float *)e->f32.p;
+    if (d_xyz_f32) {
+        // float scaling + reprojection in one launch (the float map is stored only if asked for)
+        if (!Q) return set_err(SGM_ERR_INVALID_ARG, "Q is null");
+        QMat q;
+        memcpy(q.q, Q, sizeof(q.q));
+        if ((rc = stage_begin(e, "float_xyz"))) return rc;
+        hipLaunchKernelGGL(k_float_xyz, dim3((W + 255) / 256, H), dim3(256), 0, e->stream, (const int16_t *)di, H, W, q,
+                           (float *)d_disp_f32, (float *)d_xyz_f32);
+        KCHECK();
+        if ((rc = stage_end(e, 1))) return rc;
+        return SGM_OK;
     }
     if ((rc = stage_begin(e, "to_float"))) return rc;
-    if ((rc = run_to_float(e, di, n, df))) return rc;
+    if ((rc = run_to_float(e, di, n, (float *)d_disp_f32))) return rc;
     if ((rc = stage_end(e, 1))) return rc;
-    if (d_xyz_f32) {
-        if ((rc = stage_begin(e, "reproject"))) return rc;
-        if ((rc = run_reproject(e, df, H, W, Q, 0, (float *)d_xyz_f32))) return rc;
-        if ((rc = stage_end(e, 1))) return rc;
-    }
     return SGM_OK;
 }
 
@@ -1225,7 +1227,7 @@ int sgm_median3x3(sgm_engine *e, const int16_t *src, int H, int W, int16_t *dst)
     if ((rc = e->disp_raw.ensure(npx * 2)) || (rc = e->disp_med.ensure(npx * 2))) return rc;
     HIP_TRY(hipMemcpyAsync(e->disp_raw.p, src, npx * 2, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_median3, dim3((W + 255) / 256, H), dim3(256), 0, e->stream, (const int16_t *)e->disp_raw.p,
-                       (int16_t *)e->disp_med.p, H, W);
+                       (int16_t *)e->disp_med.p, (int16_t *)nullptr, H, W);
     KCHECK();
     HIP_TRY(hipMemcpyAsync(dst, e->disp_med.p, npx * 2, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));

@@ -112,7 +112,7 @@ def test_c3_c5_4k_d256_hh_pipeline_device_with_xyz():
     assert int((got != want).sum()) == 0, f"{int((got != want).sum())} of {got.size} differ"
     assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32))      # incl. the sign of zero
     check_xyz(gxyz, wxyz)
-    assert {"sweep_dn", "sweep_up", "wta", "reproject"} <= set(names)
+    assert {"sweep_dn", "sweep_up", "wta", "float_xyz"} <= set(names)
 
 
 def test_c5_4k_d256_5path_pipeline_device_with_xyz():

@@ -285,7 +285,7 @@ def test_both_winner_take_all_forms(D, W, mode):
     p = U.params(D, 5, 0, mode, speckleWindowSize=30, speckleRange=2)
     want, t = O.sgbm_compute(l, r, taps=True, **p)
     assert t["headroom_ok"]
-    for debug in (0, 2, 256):   # 256: the int16 cost pipeline (k_hsum + k_vsum_ring) instead of the byte one
+    for debug in (0, 2, 2048, 256):   # 2 / 2048: fused / separate WTA everywhere; 256: the int16 cost pipeline (k_hsum + k_vsum_ring) instead of the byte one
         h = U.run_hip_with_taps(l, r, p, schedule=1, debug=debug)
         assert np.array_equal(h["C"], t["C"]), debug
         assert np.array_equal(h["S"], t["S"]), debug
