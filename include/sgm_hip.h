@@ -23,6 +23,8 @@
  *   sgm_remap_linear_u8  <- cv2.remap(img, map1, map2, interpolation=cv2.INTER_LINEAR)
  *                                                                    gui.py:163-164, main.ipynb cell 7
  *   sgm_compute_batch    <- the same, over N independent pairs (frame sharding unit)
+ *   sgm_get_headroom     <- (no counterpart) tells the caller whether the last compute stayed inside
+ *                           the int16 regime in which OpenCV's own arithmetic is exact
  *
  * Conventions: plain pointers and sizes, no C++ types, no exceptions across the boundary.
  * Every function returns 0 on success or a negative sgm_status; sgm_last_error() returns a

@@ -577,7 +577,12 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     else hipLaunchKernelGGL(k_prepass3_g<16>, grid, block, 0, on, g, xdir, ydir, C, bl);
                     return 1;
                 }
-                if (!(e->debug & 16) && (int64_t)g.rowsz * H < (1ll << 31)) {
+                // Narrow frames (fewer than ~1.5 lines per SIMD) are bound by the latency of one wave's
+                // instruction stream: there the single-direction kernel with one wave per (line, role) -- three
+                // times the waves, a third of the work each -- is faster (720p D=64: 0.26 against 0.34 ms); its
+                // three readers of C are served by L2 / the Infinity Cache at these sizes.
+                const bool narrow = g.W1 <= 1536 && e->prepass_rows == 0;  // (an explicit chunk height selects k_prepass3: tests)
+                if (!(e->debug & 16) && !narrow && (int64_t)g.rowsz * H < (1ll << 31)) {
                     // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant.
                     // Row chunks of about 270 rows, one launch each, base columns grouped per XCD: two of the
                     // three reads of a C pixel hit L2 (kernels_path.h).  debug 512: one chunk, plain layout (A/B).
