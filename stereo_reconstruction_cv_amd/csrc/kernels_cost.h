@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
 
     const int lane = threadIdx.x;
     const int unit = blockIdx.x;
-    const int yr = unit / nchunks, ck = unit - yr * nchunks;
+    const int yr = __builtin_amdgcn_readfirstlane(unit / nchunks), ck = unit - yr * nchunks;  // (uniform: see uniform_rsrc)
     const int y = y_base + yr;  // the launch covers rows y_base .. y_base + gridDim.x / nchunks - 1
     const int W1 = g.W1, SW2 = g.SW2, W = g.W;
     const int xs = ck * XL, xe = min(xs + XL, W1);
@@ -182,8 +182,7 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
     // this row of the output as a buffer resource; lanes past D get an out-of-range offset, so
     // their stores are dropped by the bounds check instead of by a branch
     const int row_bytes = W1 * g.D * 2;
-    const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(hsum + (int64_t)y * g.rowsz), 0, row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orow = uniform_rsrc(hsum, (int64_t)y * g.rowsz * 2, row_bytes);
     const int voff = active ? 4 * NP * lane : row_bytes;
     const int pxb = g.D * 2;
 
@@ -304,14 +303,16 @@ __global__ __launch_bounds__(64) void k_hsum(Geom g, const uint2 *__restrict__ l
 // columns), lanes span the disparities, sliding right-feature windows as in k_hsum.
 template <int NP>
 __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rplanes,
-                                            uint8_t *__restrict__ pix, int XL, int nchunks, int lrec_bytes, int seg_len)
+                                            uint8_t *__restrict__ pix, int XL, int nchunks, int lrec_bytes, int seg_len,
+                                            int y_base /* the launch covers rows y_base .. y_base + gridDim.x / nchunks - 1 */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint2 *lds_lrec = reinterpret_cast<uint2 *>(smem);
     uint8_t *seg = smem + lrec_bytes;
     const int lane = threadIdx.x;
     const int unit = blockIdx.x;
-    const int y = unit / nchunks, ck = unit - y * nchunks;
+    const int yr = __builtin_amdgcn_readfirstlane(unit / nchunks), ck = unit - yr * nchunks;  // (uniform: see uniform_rsrc)
+    const int y = y_base + yr;
     const int W1 = g.W1, W = g.W;
     const int j0 = ck * XL, j1 = min(j0 + XL, W1) - 1;
     const int nj = j1 - j0 + 1;
@@ -341,8 +342,7 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
     }
     // this row of the output; lanes past D store nowhere (offset beyond the descriptor)
     const int row_bytes = W1 * g.D;
-    const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(pix + (int64_t)y * row_bytes), 0, row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orow = uniform_rsrc(pix, (int64_t)y * row_bytes, row_bytes);
     const int voff = active ? 2 * NP * lane : row_bytes;
     int tap[6];
 #pragma unroll
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
 // register rings.  2.5 bytes read per output byte pair instead of 7: the first version (one column
 // per wave) was bound by L2 traffic.
 template <int R, int NP>
-__global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restrict__ pix, int16_t *__restrict__ C, int RB)
+__global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restrict__ pix, int16_t *__restrict__ C, int RB,
+                                                int band0 /* the launch covers bands band0 .. band0 + gridDim.y - 1 */)
 {
     constexpr int RS = R <= 1 ? 4 : (R <= 3 ? 8 : 16);  // pow2 >= 2R+2
     constexpr int XC = 4, NT = 2 * R + XC;
@@ -404,10 +405,11 @@ __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restric
     const int W1 = g.W1, D = g.D, H = g.H;
     if (x0 >= W1) return;
     const bool active = 2 * NP * lane < D;
-    const int y0 = blockIdx.y * RB, y1 = min(y0 + RB, H);
+    const int y0 = (band0 + blockIdx.y) * RB, y1 = min(y0 + RB, H);
     const int row_bytes = W1 * D;
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)pix, 0, (int)min<int64_t>((int64_t)H * row_bytes, 0x7ffffff0), 0x00020000);
+    // (the host takes this pipeline only while H * row_bytes < 2 GiB; plain 32-bit scalar arithmetic -- a
+    // min<int64_t>() here went through v_min_f64 and dragged the descriptor into VGPRs: see uniform_rsrc)
+    const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(pix, 0, H * row_bytes);
     int coff[NT];  // byte offset of the clamped neighbour columns inside a row, this lane's disparities
 #pragma unroll
     for (int t = 0; t < NT; t++) coff[t] = min(max(x0 + t - R, 0), W1 - 1) * D + 2 * NP * lane;

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
 {
     constexpr int G = 64 / GW, PB = 8;
     static_assert(GW == 64 || (NP == 1 && PARTIAL), "lane groups hold D <= 64: one packed register per lane");
-    const int lane = threadIdx.x, gi = lane / GW, li = lane % GW;
+    const int lane = threadIdx.x, gi = GW == 64 ? 0 : lane / GW, li = lane % GW;  // (GW = 64: the row must be provably uniform)
     const int W1 = g.W1, D = g.D, H = g.H;
     const int y = blockIdx.x * G + gi;
     const bool active = GW == 64 ? (!PARTIAL || 2 * NP * li < D) : (2 * NP * li < D && y < H);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
     // D <= 64 stay below 2 GiB); GW = 64: this wave's row behind the descriptor
     const int64_t span = GW == 64 ? (int64_t)row_bytes : (int64_t)H * row_bytes;
     const int64_t rowoff = GW == 64 ? (int64_t)y * row_bytes : 0;
-    const __amdgpu_buffer_rsrc_t Cv = vol_rsrc((const char *)C + rowoff, span), Sv = vol_rsrc((const char *)S + rowoff, span);
+    const __amdgpu_buffer_rsrc_t Cv = uniform_rsrc(C, rowoff, (int)span), Sv = uniform_rsrc(S, rowoff, (int)span);
     const __amdgpu_buffer_rsrc_t Sst = Sv;
     const bool stores_S = MODE != PATH_LAST || keepS;
     const int voff = active ? (GW == 64 ? 0 : y * row_bytes) + li * NP * 4 : SGM_OOB;

@@ -36,6 +36,7 @@ struct SweepArgs {
     uint2 *wta;
     int keepS;
     int dbg;  // timing experiments only (results become wrong): 64 = loader wave skips its HBM loads
+    int band0;  // the launch covers bands band0 .. band0 + gridDim.x - 1 (row-chunk pipelining of the first pass)
 };
 
 constexpr int SWEEP_MAX_ROWS = 9;  // compute waves per workgroup (640 threads -> 168 VGPRs per lane)
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     const int R = a.R;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int band = blockIdx.x;
+    const int band = a.band0 + blockIdx.x;
     const int W1 = g.W1, D = g.D, H = g.H;
     const int T = (W1 + PPS - 1) / PPS + 2 * (R - 1);  // lockstep steps
     const bool active = !PARTIAL || (2 * NP * lane < D);

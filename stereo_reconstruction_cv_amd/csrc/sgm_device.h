@@ -294,6 +294,21 @@ __device__ __forceinline__ void buf_store(const Pack<NP> &p, __amdgpu_buffer_rsr
     }
 }
 
+// Buffer descriptor from values the compiler must be able to PROVE wave-uniform (guide T20): a
+// descriptor whose words it takes for divergent -- anything derived from threadIdx, even lane / 64,
+// or from an integer division it expands in the vector unit, or merely defined behind a divergent
+// early return -- lives in VGPRs, and every buffer load / store through it is wrapped in a
+// "waterfall" loop (4 v_readfirstlane + 2 v_cmp + s_and_saveexec + branch, one memory operation at a
+// time).  Round 2 found k_box_u8, k_pix, k_hsum and the one-row-per-wave k_rows_g built that way.
+// v_readfirstlane on the base pointer and the byte count costs three instructions once per wave.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base, int64_t byte_off, int bytes)
+{
+    const uint64_t u = (uint64_t)base + (uint64_t)byte_off;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes),
+                                             0x00020000);
+}
+
 #define SGM_MAX_COST 32767
 #define SGM_SENT 0x7fff7fffu  // packed pair of MAX_COST
 

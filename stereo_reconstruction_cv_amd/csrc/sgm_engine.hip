@@ -109,7 +109,7 @@ struct sgm_engine {
     std::vector<hipEvent_t> events;
     std::vector<const char *> stage_names;
     std::vector<int> stage_launches;
-    uint64_t stage_range[SGM_MAX_STAGES] = {};  // roctx range ids of the open stages
+    std::vector<uint64_t> stage_range;   // roctx range ids of the open stages
     int nstages = 0;
 };
 
@@ -174,7 +174,7 @@ static Roctx &roctx()
 static int stage_begin(sgm_engine *e, const char *name, hipStream_t on = nullptr)
 {
     if (!e->profile) return SGM_OK;
-    if (e->nstages >= SGM_MAX_STAGES) return SGM_OK;
+    e->stage_range.resize(e->nstages + 1);
     if (roctx().start) e->stage_range[e->nstages] = roctx().start(name);
     const size_t need = (size_t)(e->nstages + 1) * 2;
     while (e->events.size() < need) {
@@ -192,7 +192,6 @@ static int stage_begin(sgm_engine *e, const char *name, hipStream_t on = nullptr
 static int stage_end(sgm_engine *e, int launches, hipStream_t on = nullptr)
 {
     if (!e->profile) return SGM_OK;
-    if (e->nstages >= SGM_MAX_STAGES) return SGM_OK;
     e->stage_launches[e->nstages] = launches;
     HIP_TRY(hipEventRecord(e->events[e->nstages * 2 + 1], on ? on : e->stream));
     if (roctx().stop) roctx().stop(e->stage_range[e->nstages]);
@@ -458,42 +457,64 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // both kernels) the int16 pipeline is faster.  debug 256: the int16 pipeline always.
         const bool byte_cost = !(e->debug & 256) && g.D > 64 && g.SW2 >= 1 && g.SW2 <= 5 && 2 * g.ftzero + 63 <= 255 &&
                                (int64_t)H * g.rowsz < (int64_t)0x7ff00000;
+        // per-pixel cost of rows [y_lo, y_hi) / block cost of the bands [band_lo, band_lo + nb) of RB rows, on stream `on`
+        auto launch_pix = [&](int y_lo, int y_hi, hipStream_t on) {
+            const int nj = XL + 2;
+            const int lrec_b = ((nj * 8) + 15) & ~15;
+            const int seg_l = (nj + 128 * g.NP + 15) & ~15;
+            const size_t lds = (size_t)lrec_b + 6 * (size_t)seg_l;
+            dim3 grid((unsigned)((int64_t)(y_hi - y_lo) * nchunks)), block(64);
+            uint8_t *px = (uint8_t *)HS;
+            if (g.NP == 1) hipLaunchKernelGGL(k_pix<1>, grid, block, lds, on, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l, y_lo);
+            else if (g.NP == 2) hipLaunchKernelGGL(k_pix<2>, grid, block, lds, on, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l, y_lo);
+            else hipLaunchKernelGGL(k_pix<4>, grid, block, lds, on, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l, y_lo);
+        };
+        auto launch_box = [&](int band_lo, int nb, hipStream_t on) {
+            dim3 grid((g.W1 + 15) / 16, nb), block(256);  // 4 waves x 4 columns per workgroup
+            const uint8_t *px = (const uint8_t *)HS;
+            int16_t *cp2 = (int16_t *)e->cost.p;
+#define SGM_BOX(R_)                                                                                        \
+    case R_:                                                                                               \
+        if (g.NP == 1) hipLaunchKernelGGL((k_box_u8<R_, 1>), grid, block, 0, on, g, px, cp2, RB, band_lo);  \
+        else if (g.NP == 2) hipLaunchKernelGGL((k_box_u8<R_, 2>), grid, block, 0, on, g, px, cp2, RB, band_lo); \
+        else hipLaunchKernelGGL((k_box_u8<R_, 4>), grid, block, 0, on, g, px, cp2, RB, band_lo);            \
+        break;
+            switch (g.SW2) {
+                SGM_BOX(1)
+                SGM_BOX(2)
+                SGM_BOX(3)
+                SGM_BOX(4)
+                SGM_BOX(5)
+            default: break;
+            }
+#undef SGM_BOX
+        };
+        // ---- schedule parameters (needed before the cost stage: the first pass may be pipelined with it)
+        // D <= 32: rows without hand-off (k_rows4_g): band height 1, the pre-pass stores every row's
+        // state; needs the 3-volume state buffer below the 4 GiB a 32-bit buffer offset reaches.
+        // (At D = 64 the fused sweep is still ahead: 720p 0.35 against 0.39 ms, and 3 V of state.)
+        const int GWs = (e->debug & 4) ? 64 : group_width(g, H);
+        const bool rows4 = GWs <= 16 && e->sweep_rows <= 0 && (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
+        const int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows);
+        const int nbands = (H + R - 1) / R;
+        const int npass = g.mode == 1 ? 2 : 1;
+        // Narrow frames (fewer than ~1.5 lines per SIMD) are bound by the latency of one wave's
+        // instruction stream: there the single-direction kernel with one wave per (line, role) -- three
+        // times the waves, a third of the work each -- is faster (720p D=64: 0.26 against 0.34 ms); its
+        // three readers of C are served by L2 / the Infinity Cache at these sizes.
+        const bool narrow = g.W1 <= 1536 && e->prepass_rows == 0;  // (an explicit chunk height selects k_prepass3: tests)
+        const bool fused_prepass = !rows4 && !(e->debug & 16) && !narrow && (int64_t)g.rowsz * H < (1ll << 31);
+        // (Running the cost stage and the downward pre-pass as a pipeline over row chunks on separate
+        // streams was built and measured in round 2: the overlapped kernels only slow each other down --
+        // cost_box 1.17 -> 2.75 ms, prepass_dn 2.05 -> 3.19 ms, frame 11.97 against 11.90 ms -- this phase
+        // of the frame is bound by HBM bandwidth, not by the order of its launches.  DESIGN.md 4.4.)
         if (byte_cost) {
             if ((rc = stage_begin(e, "cost_pix"))) return rc;
-            {
-                const int nj = XL + 2;
-                const int lrec_b = ((nj * 8) + 15) & ~15;
-                const int seg_l = (nj + 128 * g.NP + 15) & ~15;
-                const size_t lds = (size_t)lrec_b + 6 * (size_t)seg_l;
-                dim3 grid((unsigned)((int64_t)H * nchunks)), block(64);
-                uint8_t *px = (uint8_t *)HS;
-                if (g.NP == 1) hipLaunchKernelGGL(k_pix<1>, grid, block, lds, st, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l);
-                else if (g.NP == 2) hipLaunchKernelGGL(k_pix<2>, grid, block, lds, st, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l);
-                else hipLaunchKernelGGL(k_pix<4>, grid, block, lds, st, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l);
-            }
+            launch_pix(0, H, st);
             KCHECK();
             if ((rc = stage_end(e, 1))) return rc;
             if ((rc = stage_begin(e, "cost_box"))) return rc;
-            {
-                dim3 grid((g.W1 + 15) / 16, nvb), block(256);  // 4 waves x 4 columns per workgroup
-                const uint8_t *px = (const uint8_t *)HS;
-                int16_t *cp2 = (int16_t *)e->cost.p;
-#define SGM_BOX(R_)                                                                               \
-    case R_:                                                                                      \
-        if (g.NP == 1) hipLaunchKernelGGL((k_box_u8<R_, 1>), grid, block, 0, st, g, px, cp2, RB);  \
-        else if (g.NP == 2) hipLaunchKernelGGL((k_box_u8<R_, 2>), grid, block, 0, st, g, px, cp2, RB); \
-        else hipLaunchKernelGGL((k_box_u8<R_, 4>), grid, block, 0, st, g, px, cp2, RB);            \
-        break;
-                switch (g.SW2) {
-                    SGM_BOX(1)
-                    SGM_BOX(2)
-                    SGM_BOX(3)
-                    SGM_BOX(4)
-                    SGM_BOX(5)
-                default: break;
-                }
-#undef SGM_BOX
-            }
+            launch_box(0, nvb, st);
             KCHECK();
             if ((rc = stage_end(e, 1))) return rc;
         } else {
@@ -552,14 +573,6 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             if ((rc = stage_end(e, 1))) return rc;
         } else {
             // -- fused schedule: per pass a read-only boundary pre-pass (3 line scans) + one sweep
-            // D <= 32: rows without hand-off (k_rows4_g): band height 1, the pre-pass stores every row's
-            // state; needs the 3-volume state buffer below the 4 GiB a 32-bit buffer offset reaches.
-            // (At D = 64 the fused sweep is still ahead: 720p 0.35 against 0.39 ms, and 3 V of state.)
-            const int GWs = (e->debug & 4) ? 64 : group_width(g, H);
-            const bool rows4 = GWs <= 16 && e->sweep_rows <= 0 && (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
-            const int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows);
-            const int nbands = (H + R - 1) / R;
-            const int npass = g.mode == 1 ? 2 : 1;
             const size_t bnd_bytes = (size_t)nbands * g.W1 * 3 * g.D * 2;
             if (nbands > 1) {
                 if ((rc = e->bndL.ensure(bnd_bytes))) return rc;
@@ -570,6 +583,26 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             }
             // roles of the pre-pass: 0 = predecessor one step earlier in the sweep's x order
             // (x - xdir), 1 = same column, 2 = one step later
+            // one row chunk [s0, s1) (in sweep order) of the fused three-role pre-pass; chunk index c picks the
+            // ping-pong halves of the line-state buffer (kernels_path.h)
+            auto prepass_chunk = [&](int xdir, int ydir, int16_t *bl, hipStream_t on, int c, int s0, int s1, bool plain) {
+                const bool partial = g.D != 128 * g.NP;
+                const int cpx = plain ? 0 : (g.W1 + 7) / 8;
+                // (Padding the grid so that every SIMD holds the same number of waves, and halving the
+                // prefetch depth, were both measured: no change -- DESIGN.md 4.4.)
+                dim3 grid(plain ? g.W1 : 8 * cpx), block(64);
+                const size_t half = (size_t)3 * g.W1 * g.D;  // int16 elements of one state buffer
+                int16_t *sbuf = (int16_t *)(ydir > 0 ? e->pstate.p : e->pstate2.p);
+                const int16_t *sin = sbuf ? sbuf + (size_t)(c & 1) * half : nullptr;
+                int16_t *sout = sbuf ? sbuf + (size_t)((c + 1) & 1) * half : nullptr;
+#define SGM_PRE(NP_, PART_) hipLaunchKernelGGL((k_prepass3<NP_, PART_>), grid, block, 0, on, g, xdir, ydir, C, bl, R, s0, s1, sin, sout, cpx)
+                if (g.NP == 1) { if (partial) SGM_PRE(1, true); else SGM_PRE(1, false); }
+                else if (g.NP == 2) { if (partial) SGM_PRE(2, true); else SGM_PRE(2, false); }
+                else { if (partial) SGM_PRE(4, true); else SGM_PRE(4, false); }
+#undef SGM_PRE
+            };
+            // roles of the pre-pass: 0 = predecessor one step earlier in the sweep's x order
+            // (x - xdir), 1 = same column, 2 = one step later
             auto launch_prepass = [&](int xdir, int ydir, int16_t *bl, hipStream_t on) -> int {  // returns the launch count
                 if (rows4 && !(e->debug & 16)) {  // lane-grouped lines, state stored after every row
                     dim3 grid((g.W1 + 64 / GWs - 1) / (64 / GWs)), block(64);
@@ -577,38 +610,22 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     else hipLaunchKernelGGL(k_prepass3_g<16>, grid, block, 0, on, g, xdir, ydir, C, bl);
                     return 1;
                 }
-                // Narrow frames (fewer than ~1.5 lines per SIMD) are bound by the latency of one wave's
-                // instruction stream: there the single-direction kernel with one wave per (line, role) -- three
-                // times the waves, a third of the work each -- is faster (720p D=64: 0.26 against 0.34 ms); its
-                // three readers of C are served by L2 / the Infinity Cache at these sizes.
-                const bool narrow = g.W1 <= 1536 && e->prepass_rows == 0;  // (an explicit chunk height selects k_prepass3: tests)
-                if (!(e->debug & 16) && !narrow && (int64_t)g.rowsz * H < (1ll << 31)) {
+                if (fused_prepass) {
                     // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant.
                     // Row chunks of about 270 rows, one launch each, base columns grouped per XCD: two of the
                     // three reads of a C pixel hit L2 (kernels_path.h).  debug 512: one chunk, plain layout (A/B).
-                    const bool partial = g.D != 128 * g.NP;
                     const bool plain = (e->debug & 512) != 0;
                     const int nch = plain ? 1 : (e->prepass_rows > 0 ? (H + e->prepass_rows - 1) / e->prepass_rows
                                                                           : std::max(1, (H + 135) / 270));
                     const int Hc = (H + nch - 1) / nch;
-                    const int cpx = plain ? 0 : (g.W1 + 7) / 8;
-                    // (Padding the grid so that every SIMD holds the same number of waves, and halving the
-                    // prefetch depth, were both measured: no change -- DESIGN.md 4.4.)
-                    dim3 grid(plain ? g.W1 : 8 * cpx), block(64);
-                    const size_t half = (size_t)3 * g.W1 * g.D;  // int16 elements of one state buffer
-                    int16_t *sbuf = (int16_t *)(ydir > 0 ? e->pstate.p : e->pstate2.p);
+                    int n = 0;
                     for (int c = 0; c < nch; c++) {
                         const int s0 = c * Hc, s1 = std::min(H, s0 + Hc);
                         if (s0 >= s1) break;
-                        const int16_t *sin = sbuf ? sbuf + (size_t)(c & 1) * half : nullptr;
-                        int16_t *sout = sbuf ? sbuf + (size_t)((c + 1) & 1) * half : nullptr;
-#define SGM_PRE(NP_, PART_) hipLaunchKernelGGL((k_prepass3<NP_, PART_>), grid, block, 0, on, g, xdir, ydir, C, bl, R, s0, s1, sin, sout, cpx)
-                        if (g.NP == 1) { if (partial) SGM_PRE(1, true); else SGM_PRE(1, false); }
-                        else if (g.NP == 2) { if (partial) SGM_PRE(2, true); else SGM_PRE(2, false); }
-                        else { if (partial) SGM_PRE(4, true); else SGM_PRE(4, false); }
-#undef SGM_PRE
+                        prepass_chunk(xdir, ydir, bl, on, c, s0, s1, plain);
+                        n++;
                     }
-                    return nch;
+                    return n;
                 }
                 // one launch of the single-direction kernel, grid.y = role
                 Boundary bd{bl, R, 0};
@@ -659,7 +676,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 // winner-take-all: fused into the last path kernel (debug 2), or -- default -- a
                 // separate pass over S with one lane per pixel (k_wta_t)
                 const bool last = pass == npass - 1 && g.mode == 1 && fused_wta && !rows4;
-                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug};
+                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug, 0};
                 if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up")))) return rc;
                 if (rows4) {
                     dim3 grid((H + 64 / GWs - 1) / (64 / GWs)), block(64);
@@ -1300,22 +1317,32 @@ int sgm_get_stage_times(sgm_engine *e, sgm_stage_times *out)
     if (!e->profile) return set_err(SGM_ERR_INVALID_ARG, "SGM_OPT_PROFILE is off");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    out->n = e->nstages;
+    // one entry per stage NAME: a stage may consist of several bracketed launches (row chunks of the
+    // pipelined first pass, on streams of their own) -- their HIP-event times and launch counts add up
+    out->n = 0;
     for (int i = 0; i < e->nstages; i++) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e->events[i * 2], e->events[i * 2 + 1]));
-        out->name[i] = e->stage_names[i];
-        out->ms[i] = ms;
-        out->launches[i] = e->stage_launches[i];
+        int k = 0;
+        while (k < out->n && strcmp(out->name[k], e->stage_names[i]) != 0) k++;
+        if (k == out->n) {
+            if (out->n >= SGM_MAX_STAGES - 1) continue;
+            out->name[k] = e->stage_names[i];
+            out->ms[k] = 0.f;
+            out->launches[k] = 0;
+            out->n++;
+        }
+        out->ms[k] += ms;
+        out->launches[k] += e->stage_launches[i];
     }
-    // stages may overlap (auxiliary stream): also report first-begin -> last-end of the main stream
-    if (e->nstages > 0 && e->nstages < SGM_MAX_STAGES) {
+    // stages overlap (auxiliary / chunk streams): also report first-begin -> last-end of the main stream
+    if (e->nstages > 0) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e->events[0], e->events[(e->nstages - 1) * 2 + 1]));
-        out->name[e->nstages] = "_wall";
-        out->ms[e->nstages] = ms;
-        out->launches[e->nstages] = 0;
-        out->n = e->nstages + 1;
+        out->name[out->n] = "_wall";
+        out->ms[out->n] = ms;
+        out->launches[out->n] = 0;
+        out->n++;
     }
     return SGM_OK;
 }

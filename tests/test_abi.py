@@ -99,3 +99,28 @@ def test_no_wide_buffer_stores_in_the_kernel_isa():
     assert not re.search(r"buffer_store_dwordx[34]", text)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py"), isa], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_no_waterfall_loops_around_buffer_operations_in_the_hot_kernels():
+    """A buffer descriptor the compiler cannot prove wave-uniform makes it wrap EVERY buffer load /
+    store in a "waterfall" loop (v_readfirstlane x4, v_cmp, s_and_saveexec, branch -- one memory
+    operation at a time).  Round 2 found k_box_u8 (160 of them), k_pix, k_hsum and the one-row-per-wave
+    k_rows_g built that way and fixed the descriptors (sgm_device.h: uniform_rsrc).  Checked on the
+    ISA of the current build: none in the path / sweep / cost kernels, a handful (one row fetch per
+    band) tolerated in k_box_u8."""
+    import subprocess
+    csrc = os.path.join(ROOT, "stereo_reconstruction_cv_amd", "csrc")
+    text = open(os.path.join(csrc, "sgm_engine.s")).read()
+    worst = {}
+    for km in re.finditer(r"^(_Z\w+):\s*; @", text, flags=re.M):
+        name = km.group(1)
+        body = text[km.end():text.index(".Lfunc_end", km.end())].split("\n")
+        n = sum(1 for i, l in enumerate(body) if "s_and_saveexec_b64" in l and
+                re.search(r"buffer_(load|store)", " ".join(body[i + 1:i + 3])))
+        if n:
+            worst[name] = n
+    for name, n in worst.items():
+        if "k_box_u8" in name:
+            assert n <= 14, (name, n)
+        else:
+            assert not re.search(r"k_sweep|k_prepass3|k_pix|k_hsum|k_path|k_wta_t|k_rows_gILi64", name), (name, n)
