@@ -350,14 +350,14 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
     int recp = 0;
     asm volatile("" : "+v"(recp));  // keep the (wave-uniform) record in VGPRs: v_perm splats, no scalar unpack
     int so = j0 * g.D;
-    for (int j = j0; j <= j1; j++) {
-        if (j > j0) {
+    // one column: shift the six windows by the new bytes nw[] (not for the chunk's first column), cost, store
+    auto column = [&](int j, bool shift, const uint32_t (&nw)[6]) {
+        if (shift) {
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                const uint32_t nw = seg[tap[c] - (j - j0)];
 #pragma unroll
                 for (int i = NP - 1; i >= 1; i--) w[c][i] = __builtin_amdgcn_alignbit(w[c][i], w[c][i - 1], 16);
-                w[c][0] = (w[c][0] << 16) | nw;
+                w[c][0] = (w[c][0] << 16) | nw[c];
             }
         }
         const uint2 rec = lds_lrec[recp + (j - j0)];
@@ -382,6 +382,26 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
             __builtin_amdgcn_raw_buffer_store_b64(o, orow, voff, so, 0);
         }
         so += g.D;
+    };
+    const uint32_t none[6] = {0, 0, 0, 0, 0, 0};
+    column(j0, false, none);
+    int j = j0 + 1;
+    // four columns per iteration: their 24 window bytes are read first (one counted wait instead of a
+    // full lgkmcnt(0) drain per column), then the four columns are computed from registers
+    for (; j + 3 <= j1; j += 4) {
+        uint32_t nb[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) nb[u][c] = seg[tap[c] - (j + u - j0)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) column(j + u, true, nb[u]);
+    }
+    for (; j <= j1; j++) {
+        uint32_t nb[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) nb[c] = seg[tap[c] - (j - j0)];
+        column(j, true, nb);
     }
 }
 

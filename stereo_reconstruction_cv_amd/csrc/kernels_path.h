@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
         for (int d = 0; d < 3; d++) path_elem<NP, PARTIAL>(c3[d], L[d], P1s, P2s, active, N[d], r[d], sr[d]);
         const uint32_t m01 = wave_min_pk(pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])));
         const uint32_t m2 = halves_min(wave_min_pk(r[2]));
-        hm_hi = max(hm_hi, m01);  // headroom record (scalar; see k_sweep)
+        hm_hi = max(hm_hi, m01);  // headroom record (see k_sweep; this kernel is bound by memory, not by issue)
         hm_lo = max(hm_lo, max(m01 & 0xffffu, m2));
         path_normalise<NP, PARTIAL>(N[0], m01 & 0xffffu, active, L[0]);
         path_normalise<NP, PARTIAL>(N[1], m01 >> 16, active, L[1]);

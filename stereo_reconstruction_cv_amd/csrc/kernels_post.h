@@ -95,13 +95,15 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
     // chunk c = lane + 64 k of the block's contiguous 64 * D * 2 bytes: loads with a clamped index
     // (no branch between them), committed to the padded LDS rows afterwards
     auto issue = [&](int64_t blk, int k0) {
-        const int total = (int)min<int64_t>(64, npix - blk * 64) * cpr;
+        const int64_t left = npix - blk * 64;  // (integer compare: min<int64_t>() goes through v_min_f64)
+        const int total = (left < 64 ? (int)left : 64) * cpr;
         const uint4 *src = reinterpret_cast<const uint4 *>(S + blk * 64 * D);
 #pragma unroll
         for (int u = 0; u < PF; u++) v[u] = src[min(lane + 64 * (k0 + u), total - 1)];
     };
     auto commit = [&](int64_t blk, int k0) {
-        const int total = (int)min<int64_t>(64, npix - blk * 64) * cpr;
+        const int64_t left = npix - blk * 64;
+        const int total = (left < 64 ? (int)left : 64) * cpr;
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int c = lane + 64 * (k0 + u);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
     if (LG >= 0 && blk < nblocks) issue(blk, 0);
     for (; blk < nblocks; blk += gridDim.x) {
     const int64_t p0 = blk * 64;
-    const int np = (int)min<int64_t>(64, npix - p0);
+    const int np = npix - p0 < 64 ? (int)(npix - p0) : 64;
     __syncthreads();  // (one wave per block: orders the LDS traffic of consecutive blocks)
     if (LG >= 0) {
         commit(blk, 0);

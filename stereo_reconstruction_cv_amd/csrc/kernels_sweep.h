@@ -300,8 +300,10 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         path_elem<NP, PARTIAL>(Cp, QC, P1s, P2s, active, NC, rC, srC);
         const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));  // {min 0, min A}
         const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));  // {min B, min C}
-        hm_hi = max(hm_hi, max(m0A, mBC));
-        hm_lo = max(hm_lo, max(m0A & 0xffffu, mBC & 0xffffu));
+        smax_u32(hm_hi, m0A);
+        smax_u32(hm_hi, mBC);
+        smax_u32(hm_lo, m0A & 0xffffu);
+        smax_u32(hm_lo, mBC & 0xffffu);
         Pack<NP> LA, LB, LC;
         path_normalise<NP, PARTIAL>(N0, m0A & 0xffffu, active, L0);
         path_normalise<NP, PARTIAL>(NA, m0A >> 16, active, LA);

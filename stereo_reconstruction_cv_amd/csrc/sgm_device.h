@@ -114,6 +114,13 @@ __device__ __forceinline__ void headroom_commit_pk(uint32_t *hr, int slot, uint3
     if (hr && lane_id() == 0) atomicMax(hr + slot, m);
 }
 
+// acc = max(acc, x) on the scalar unit (both wave-uniform).  Written as asm: left to the compiler a chain
+// of such maxima turns into v_max3_u32 in the vector stream of the issue-bound kernels that use it.
+__device__ __forceinline__ void smax_u32(uint32_t &acc, uint32_t x)
+{
+    asm("s_max_u32 %0, %0, %1" : "+s"(acc) : "s"(__builtin_amdgcn_readfirstlane(x)));  // (folded away when x is scalar already)
+}
+
 // N independent reductions with their DPP steps interleaved: a DPP read needs two wait states
 // after the VALU write of its source, which a second chain fills (a lone chain gets s_nop's).
 template <int N> __device__ __forceinline__ void wave_min_pk_n(uint32_t (&x)[N])
