@@ -118,7 +118,8 @@ __device__ __forceinline__ void headroom_commit_pk(uint32_t *hr, int slot, uint3
 // of such maxima turns into v_max3_u32 in the vector stream of the issue-bound kernels that use it.
 __device__ __forceinline__ void smax_u32(uint32_t &acc, uint32_t x)
 {
-    asm("s_max_u32 %0, %0, %1" : "+s"(acc) : "s"(__builtin_amdgcn_readfirstlane(x)));  // (folded away when x is scalar already)
+    // (s_max_u32 writes SCC: it must be declared, or the compiler keeps a compare result across the statement)
+    asm("s_max_u32 %0, %0, %1" : "+s"(acc) : "s"(__builtin_amdgcn_readfirstlane(x)) : "scc");
 }
 
 // N independent reductions with their DPP steps interleaved: a DPP read needs two wait states
