@@ -97,7 +97,9 @@ typedef enum {
                               * pre-pass right after the cost stage;  256: int16 cost pipeline (k_hsum +
                               * k_vsum_ring) instead of the byte one;  512: boundary pre-pass in one chunk
                               * with the plain line-per-block layout (no XCD grouping);  2048: winner-take-all
-                              * always as its own pass */
+                              * always as its own pass;  4096: D <= 64 with the three-role grouped pre-pass and
+                              * the four-direction row kernel (round 1) instead of per-role pre-pass + element-wise
+                              * vertical kernel + in-row kernel;  8192: that small-D schedule for D <= 32 only */
 } sgm_option;
 
 #define SGM_MAX_STAGES 32

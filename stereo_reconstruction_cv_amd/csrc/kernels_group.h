@@ -243,11 +243,14 @@ __global__ __launch_bounds__(64) void k_rows4_g(Geom g, int xdir, int ydir, cons
 // each (rx = +xdir, 0, -xdir), diagonals wrap around the side border with a state reset -- but every
 // lane group has its own line, so columns, wraps and addresses are per-lane values handled without
 // branches; C rows are prefetched PF rows ahead through a statically indexed register ring.
-template <int GW>
+// SPLIT: one role per wave (role = blockIdx.y, grid.y = 3): three times the waves, a third of the work
+// each -- frames of small D have so few lines per SIMD that a wave's instruction latency bounds them.
+template <int GW, bool SPLIT>
 __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
                                                    int16_t *__restrict__ bnd)
 {
     constexpr int G = 64 / GW, NP = 1, PF = 8;
+    constexpr int NR = SPLIT ? 1 : 3;  // roles handled by this wave
     constexpr int OOB = (int)0xfffffff0u;
     const int lane = threadIdx.x, gi = lane / GW, li = lane % GW;
     const int W1 = g.W1, D = g.D, H = g.H;
@@ -262,25 +265,28 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
     const __amdgpu_buffer_rsrc_t Bv = __builtin_amdgcn_make_buffer_rsrc((void *)bnd, 0, (int)(3u * vol), 0x00020000);
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     const uint32_t init = active ? 0u : SGM_SENT;
-    const int rx[3] = {xdir, 0, -xdir};
-    const int y0 = ydir > 0 ? 0 : H - 1;
-    int xl[3], xc[3];  // per lane: column of the load cursor (PF rows ahead) and of the compute cursor
+    const int role0 = SPLIT ? (int)blockIdx.y : 0;  // first (only) role of this wave
+    int rx[NR];
 #pragma unroll
-    for (int d = 0; d < 3; d++) xl[d] = xc[d] = min(line, W1 - 1);
+    for (int d = 0; d < NR; d++) rx[d] = (role0 + d) == 0 ? xdir : ((role0 + d) == 1 ? 0 : -xdir);
+    const int y0 = ydir > 0 ? 0 : H - 1;
+    int xl[NR], xc[NR];  // per lane: column of the load cursor (PF rows ahead) and of the compute cursor
+#pragma unroll
+    for (int d = 0; d < NR; d++) xl[d] = xc[d] = min(line, W1 - 1);
     auto wrapped = [&](int &x) {  // left the image -> re-enter on the other side
         const bool w = x >= W1 || x < 0;
         x = x >= W1 ? 0 : (x < 0 ? W1 - 1 : x);
         return w;
     };
-    Pack<NP> L[3], cv[PF][3];
+    Pack<NP> L[NR], cv[PF][NR];
 #pragma unroll
-    for (int d = 0; d < 3; d++) L[d].fill(init);
-    ShiftRegs sr[3];
+    for (int d = 0; d < NR; d++) L[d].fill(init);
+    ShiftRegs sr[NR];
     uint32_t hm = 0;
     auto issue = [&](Pack<NP> *c3, int s) {  // C of sweep-order row s at the load cursors, then advance them
         const int rowoff = (y0 + s * ydir) * row_bytes;
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
+        for (int d = 0; d < NR; d++) {
             const int off = (active && s < H) ? rowoff + xl[d] * pxb + li * 4 : OOB;
             buf_load<NP>(c3[d], Cv, off, 0);
             xl[d] += rx[d];
@@ -290,21 +296,28 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
 #pragma unroll
     for (int u = 0; u < PF; u++) issue(cv[u], u);
     auto row = [&](int u, int s) {
-        Pack<NP> N[3];
-        uint32_t r[3];
+        Pack<NP> N[NR];
+        uint32_t r[NR];
 #pragma unroll
-        for (int d = 0; d < 3; d++) path_elem<NP, true, GW>(cv[u][d], L[d], P1s, P2s, active, N[d], r[d], sr[d], ge);
-        uint32_t mm[2] = {pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])), r[2]};
-        group_min_pk_n<GW, 2>(mm);
-        const uint32_t m2 = min(mm[1] & 0xffffu, mm[1] >> 16);
-        if (s < H) hm = max(hm, max(max(mm[0] & 0xffffu, mm[0] >> 16), m2));  // headroom record of the three directions
-        path_normalise<NP, true>(N[0], mm[0] & 0xffffu, active, L[0]);
-        path_normalise<NP, true>(N[1], mm[0] >> 16, active, L[1]);
-        path_normalise<NP, true>(N[2], m2, active, L[2]);
+        for (int d = 0; d < NR; d++) path_elem<NP, true, GW>(cv[u][d], L[d], P1s, P2s, active, N[d], r[d], sr[d], ge);
+        if constexpr (SPLIT) {
+            const uint32_t mm = group_min_pk<GW>(r[0]);
+            const uint32_t m0 = min(mm & 0xffffu, mm >> 16);
+            if (s < H) hm = max(hm, m0);
+            path_normalise<NP, true>(N[0], m0, active, L[0]);
+        } else {
+            uint32_t mm[2] = {pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])), r[2]};
+            group_min_pk_n<GW, 2>(mm);
+            const uint32_t m2 = min(mm[1] & 0xffffu, mm[1] >> 16);
+            if (s < H) hm = max(hm, max(max(mm[0] & 0xffffu, mm[0] >> 16), m2));  // headroom record of the three directions
+            path_normalise<NP, true>(N[0], mm[0] & 0xffffu, active, L[0]);
+            path_normalise<NP, true>(N[1], mm[0] >> 16, active, L[1]);
+            path_normalise<NP, true>(N[2], m2, active, L[2]);
+        }
         // the state the row s + 1 will read: bnd[s + 1][column][role][D]
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const int off = (active && s + 1 < H) ? (int)(((uint32_t)(s + 1) * (uint32_t)W1 + (uint32_t)xc[d]) * 3u + (uint32_t)d) * pxb + li * 4 : OOB;
+        for (int d = 0; d < NR; d++) {
+            const int off = (active && s + 1 < H) ? (int)(((uint32_t)(s + 1) * (uint32_t)W1 + (uint32_t)xc[d]) * 3u + (uint32_t)(role0 + d)) * pxb + li * 4 : OOB;
             buf_store<NP>(L[d], Bv, off, 0);
             xc[d] += rx[d];
             if (wrapped(xc[d])) L[d].fill(init);  // (per lane: a select)
@@ -320,6 +333,71 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
     for (int u = 0; u < PF; u++)
         if (s0 + u < H) row(u, s0 + u);
     headroom_commit_pk(g.hr, 1, active ? hm : 0u);
+}
+
+// The three directions that come from the previous row, for EVERY pixel at once (D <= 64, band height 1):
+// with the boundary pre-pass having left every row's three predecessor states in HBM, these paths need
+// no recurrence here at all -- N_r(p, d) = C(p, d) + min(Q_r(d), Q_r(d +- 1) + P1, P2) is element-wise --
+// so the kernel is a plain streaming pass over all pixels (one lane group per pixel) instead of a walk
+// along the rows: S = sat(N_A + N_B + N_C [+ S]).  The in-row direction then runs as k_rows_g (ACCUM).
+// Same arithmetic as k_rows4_g without its in-row path.  MODE: PATH_FIRST / PATH_ACCUM.
+template <int GW, int MODE>
+__global__ __launch_bounds__(256) void k_vert3_g(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
+                                                 int16_t *__restrict__ S, const int16_t *__restrict__ bnd)
+{
+    constexpr int G = 64 / GW, NP = 1;
+    constexpr int OOB = (int)0xfffffff0u;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gi = lane / GW, li = lane % GW;
+    const int W1 = g.W1, D = g.D, H = g.H;
+    const int j = blockIdx.y;  // row index in sweep order
+    const int y = ydir > 0 ? j : H - 1 - j;
+    const int xb = (blockIdx.x * 4 + wv) * 64;  // this wave's 64 consecutive columns
+    GroupEdge ge;
+    ge.first = li == 0;
+    ge.last = li == GW - 1;
+    const int pxb = D * 2, row_bytes = W1 * pxb;
+    const uint32_t vol = (uint32_t)H * (uint32_t)row_bytes;
+    const __amdgpu_buffer_rsrc_t Cv = __builtin_amdgcn_make_buffer_rsrc((void *)C, 0, (int)vol, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Sv = __builtin_amdgcn_make_buffer_rsrc((void *)S, 0, (int)vol, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Bv = __builtin_amdgcn_make_buffer_rsrc((void *)bnd, 0, (int)(3u * vol), 0x00020000);
+    const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
+    const bool lanes = 2 * li < D;
+    const bool has_prev = j > 0;
+    const uint32_t rowoff = (uint32_t)y * (uint32_t)row_bytes, brow = (uint32_t)j * 3u * (uint32_t)row_bytes;
+    ShiftRegs srA, srB, srC;
+#pragma unroll 4
+    for (int it = 0; it < GW; it++) {  // G pixels per iteration, 64 per wave
+        const int x = xb + it * G + gi;
+        const bool active = lanes && x < W1;
+        const int k = xdir > 0 ? x : W1 - 1 - x;  // position in the sweep's order: role A comes from k - 1, C from k + 1
+        const int xa = min(max(x - xdir, 0), W1 - 1), xc = min(max(x + xdir, 0), W1 - 1);
+        const int voff = active ? (int)(rowoff + (uint32_t)x * pxb) + li * 4 : OOB;
+        const bool rd = active && has_prev;
+        Pack<NP> c, sp, QA, QB, QC;
+        buf_load<NP>(c, Cv, voff, 0);
+        if (MODE == PATH_ACCUM) buf_load<NP>(sp, Sv, voff, 0);
+        buf_load<NP>(QA, Bv, rd ? (int)(brow + (uint32_t)(xa * 3 + 0) * pxb) + li * 4 : OOB, 0);
+        buf_load<NP>(QB, Bv, rd ? (int)(brow + (uint32_t)(x * 3 + 1) * pxb) + li * 4 : OOB, 0);
+        buf_load<NP>(QC, Bv, rd ? (int)(brow + (uint32_t)(xc * 3 + 2) * pxb) + li * 4 : OOB, 0);
+        // out-of-image predecessors and idle lanes: start state / sentinel
+        if (k == 0) QA.fill(0u);
+        if (k == W1 - 1) QC.fill(0u);
+        if (!active) {
+            QA.fill(SGM_SENT);
+            QB.fill(SGM_SENT);
+            QC.fill(SGM_SENT);
+        }
+        Pack<NP> NA, NB, NC;
+        uint32_t rA, rB, rC;
+        path_elem<NP, true, GW>(c, QA, P1s, P2s, active, NA, rA, srA, ge);
+        path_elem<NP, true, GW>(c, QB, P1s, P2s, active, NB, rB, srB, ge);
+        path_elem<NP, true, GW>(c, QC, P1s, P2s, active, NC, rC, srC, ge);
+        Pack<NP> Sn;
+        uint32_t v = pk_adds_s(pk_adds_s(NA.r[0], NB.r[0]), NC.r[0]);
+        if (MODE == PATH_ACCUM) v = pk_adds_s(v, sp.r[0]);
+        Sn.r[0] = v;
+        buf_store<NP>(Sn, Sv, voff, 0);
+    }
 }
 
 }  // namespace sgm

@@ -494,7 +494,9 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // state; needs the 3-volume state buffer below the 4 GiB a 32-bit buffer offset reaches.
         // (At D = 64 the fused sweep is still ahead: 720p 0.35 against 0.39 ms, and 3 V of state.)
         const int GWs = (e->debug & 4) ? 64 : group_width(g, H);
-        const bool rows4 = GWs <= 16 && e->sweep_rows <= 0 && (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
+        // debug 8192: D <= 32 only (the round-1 limit; A/B)
+        const bool rows4 = GWs <= ((e->debug & 8192) ? 16 : 32) && e->sweep_rows <= 0 &&
+                           (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
         const int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows);
         const int nbands = (H + R - 1) / R;
         const int npass = g.mode == 1 ? 2 : 1;
@@ -605,9 +607,19 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // (x - xdir), 1 = same column, 2 = one step later
             auto launch_prepass = [&](int xdir, int ydir, int16_t *bl, hipStream_t on) -> int {  // returns the launch count
                 if (rows4 && !(e->debug & 16)) {  // lane-grouped lines, state stored after every row
-                    dim3 grid((g.W1 + 64 / GWs - 1) / (64 / GWs)), block(64);
-                    if (GWs == 8) hipLaunchKernelGGL(k_prepass3_g<8>, grid, block, 0, on, g, xdir, ydir, C, bl);
-                    else hipLaunchKernelGGL(k_prepass3_g<16>, grid, block, 0, on, g, xdir, ydir, C, bl);
+                    // one role per wave (grid.y = 3): these frames have too few lines to fill the SIMDs with
+                    // three-role waves (4K D=16: 478); debug 4096: the three roles fused in one wave (A/B)
+                    const bool split = !(e->debug & 4096);
+                    dim3 grid((g.W1 + 64 / GWs - 1) / (64 / GWs), split ? 3 : 1), block(64);
+#define SGM_PREG(GW_)                                                                                              \
+    do {                                                                                                           \
+        if (split) hipLaunchKernelGGL((k_prepass3_g<GW_, true>), grid, block, 0, on, g, xdir, ydir, C, bl);        \
+        else hipLaunchKernelGGL((k_prepass3_g<GW_, false>), grid, block, 0, on, g, xdir, ydir, C, bl);             \
+    } while (0)
+                    if (GWs == 8) SGM_PREG(8);
+                    else if (GWs == 16) SGM_PREG(16);
+                    else SGM_PREG(32);
+#undef SGM_PREG
                     return 1;
                 }
                 if (fused_prepass) {
@@ -678,7 +690,23 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 const bool last = pass == npass - 1 && g.mode == 1 && fused_wta && !rows4;
                 SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug, 0};
                 if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up")))) return rc;
-                if (rows4) {
+                if (rows4 && !(e->debug & 4096)) {
+                    // D <= 64, band height 1: the three directions from the previous row are element-wise given the
+                    // pre-pass state of every row (k_vert3_g, one streaming pass over all pixels); only the in-row
+                    // direction is a recurrence (k_rows_g, S +=)
+                    dim3 grid((g.W1 + 255) / 256, H), block(256);
+                    const int16_t *bq = (const int16_t *)bl;
+#define SGM_VERT(GW_)                                                                                            \
+    do {                                                                                                         \
+        if (pass == 0) hipLaunchKernelGGL((k_vert3_g<GW_, PATH_FIRST>), grid, block, 0, st, g, xdir, ydir, C, S, bq); \
+        else hipLaunchKernelGGL((k_vert3_g<GW_, PATH_ACCUM>), grid, block, 0, st, g, xdir, ydir, C, S, bq);      \
+    } while (0)
+                    if (GWs == 8) SGM_VERT(8);
+                    else if (GWs == 16) SGM_VERT(16);
+                    else SGM_VERT(32);
+#undef SGM_VERT
+                    launch_rows_grouped(g, H, GWs, xdir, PATH_ACCUM, C, S, 1, wta, st);
+                } else if (rows4) {  // debug 4096: all four directions in one walk along the rows (round 1)
                     dim3 grid((H + 64 / GWs - 1) / (64 / GWs)), block(64);
                     const int16_t *bq = (const int16_t *)bl;
 #define SGM_ROWS4(GW_)                                                                                          \
