@@ -54,8 +54,11 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
     uint2 *const wrow = wta + ((int64_t)min(y, H - 1) * g.W + g.minX1);  // per lane; idle groups never store
     const int lw = y < H ? li : GW;  // "lane" for the WTA: a group past the last row must not own a record
 
-    Pack<NP> L;
-    L.fill(init);
+    // un-normalised state U = L_r(q, .) and its minimum (both halves of ms): the form with the short
+    // dependency chain between pixels (path_inner_min / path_finish, kernels_path.h)
+    Pack<NP> U;
+    U.fill(init);
+    uint32_t ms = 0;
     ShiftRegs sr;
     uint32_t hm = 0;  // headroom record: largest min_d L_r(p, d) of this lane's row
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
@@ -71,19 +74,21 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
             }
     };
     auto pixel = [&](const Pack<NP> &cv, const Pack<NP> &sv, int k) {
-        Pack<NP> Ln, Lnorm;
+        Pack<NP> t, Un;
         uint32_t rmin;
-        path_elem<NP, PARTIAL, GW>(cv, L, P1s, P2s, active, Ln, rmin, sr, ge);
+        path_inner_min<NP, PARTIAL, GW>(U, P1s, t, sr, ge);
+        path_finish<NP, PARTIAL>(cv, t, ms, P2s, active, Un, rmin);
         const uint32_t m = group_min_pk<GW>(rmin);
         const uint32_t mL = min(m & 0xffffu, m >> 16);
         hm = max(hm, mL);
-        path_normalise<NP, PARTIAL>(Ln, mL, active, Lnorm);
+        ms = splat16(mL);
+        if (PARTIAL && !active) ms = 0;  // (idle lanes: keep their sentinel arithmetic away from wrap-around)
         Pack<NP> Sn;
 #pragma unroll
-        for (int i = 0; i < NP; i++) Sn.r[i] = MODE == PATH_FIRST ? Ln.r[i] : pk_adds_s(sv.r[i], Ln.r[i]);
+        for (int i = 0; i < NP; i++) Sn.r[i] = MODE == PATH_FIRST ? Un.r[i] : pk_adds_s(sv.r[i], Un.r[i]);
         const int x = x0 + k * rx;
         if (stores_S) buf_store<NP>(Sn, Sst, voff, x * pxb);
-        L = Lnorm;
+        U = Un;
         return Sn;
     };
     auto compute_t = [&](auto full_c, Pack<NP> *cb, Pack<NP> *sb, int k0) {

@@ -71,6 +71,48 @@ __device__ __forceinline__ void path_elem(const Pack<NP> &Cp, const Pack<NP> &Lq
     }
 }
 
+// The same recurrence on UN-normalised state, for kernels whose speed is the latency of one line's
+// dependency chain (the in-row kernels k_rows_g).  With U = L_r(q, .) itself and m = min_k U(k):
+//     L_r(p,d) = C(p,d) + min( min(U(d), U(d-1)+P1, U(d+1)+P1) - m, P2 )
+// The inner minimum t(d) does not need m, so it is computed while the reduction that yields m is still
+// running; only "t - m, min P2, + C" (3 dependent operations instead of 9) sit between one pixel's
+// reduction and the next.  Exact in integers: t >= m, and a saturated U(d+-1)+P1 never wins the
+// minimum against U(d) <= 32767.
+template <int NP, bool PARTIAL, int GW = 64>
+__device__ __forceinline__ void path_inner_min(const Pack<NP> &U, uint32_t P1s, Pack<NP> &t, ShiftRegs &sr,
+                                               GroupEdge ge = GroupEdge())
+{
+    sr.up = from_lower_lane(U.r[NP - 1], sr.up);
+    sr.dn = from_upper_lane(U.r[0], sr.dn);
+    uint32_t up = sr.up, dn = sr.dn;
+    if (GW < 64) {
+        up = ge.first ? SGM_SENT : up;
+        dn = ge.last ? SGM_SENT : dn;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const uint32_t prevp = i == 0 ? up : U.r[i - 1];
+        const uint32_t nextp = i == NP - 1 ? dn : U.r[i + 1];
+        const uint32_t lm1 = __builtin_amdgcn_alignbit(U.r[i], prevp, 16);
+        const uint32_t lp1 = __builtin_amdgcn_alignbit(nextp, U.r[i], 16);
+        t.r[i] = pk_min_s(pk_adds_s(pk_min_s(lm1, lp1), P1s), U.r[i]);
+    }
+}
+// U(p, .) from t, the splat minimum ms = {m, m} of the previous pixel and the cost; rmin as in path_elem
+template <int NP, bool PARTIAL>
+__device__ __forceinline__ void path_finish(const Pack<NP> &Cp, const Pack<NP> &t, uint32_t ms, uint32_t P2s, bool active,
+                                            Pack<NP> &Un, uint32_t &rmin)
+{
+    rmin = SGM_SENT;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        uint32_t v = pk_add(Cp.r[i], pk_min_s(pk_sub(t.r[i], ms), P2s));
+        if (PARTIAL) v = active ? v : SGM_SENT;
+        Un.r[i] = v;
+        rmin = pk_min_s(rmin, v);
+    }
+}
+
 // Ln - m on active lanes (m: wave-uniform minimum); idle lanes keep the sentinel
 template <int NP, bool PARTIAL>
 __device__ __forceinline__ void path_normalise(const Pack<NP> &Ln, uint32_t m, bool active, Pack<NP> &out)

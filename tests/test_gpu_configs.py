@@ -160,6 +160,19 @@ def test_c4_batch_1080p_d128_both_batch_entries():
     assert np.array_equal(d3, d2[:2])
 
 
+@pytest.mark.parametrize("D,mode", [(64, 1), (32, 0)])
+def test_4k_small_d_schedule(D, mode):
+    """D <= 64 takes its own schedule (per-role grouped pre-pass with band height 1, element-wise
+    vertical kernel, in-row kernels): at 4K its boundary-state buffer is 3 volumes (3.1 GB at D = 64,
+    32-bit offsets beyond 2^31) -- full size, both modes."""
+    H, W = 2160, 3840
+    l, r = pair(H, W, D, 1234)
+    p = nb_params(D, 7, mode)
+    want, _, _ = oracle_frame(l, r, p)
+    got, _, _, names = run_pipeline_device(l, r, p, None)
+    assert int((got != want).sum()) == 0, f"{int((got != want).sum())} of {got.size} differ"
+
+
 def test_notebook_setting_4k_d16_bs11():
     """The notebook as run (main.ipynb:781: ndisp=16, mindis=0, blockSize=11) on a 4K synthetic
     pair through the notebook-shaped functions.  bs=11 / P2=11616 is outside the worst-case
