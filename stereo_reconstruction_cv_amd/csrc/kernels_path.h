@@ -113,17 +113,21 @@ __device__ __forceinline__ void path_finish(const Pack<NP> &Cp, const Pack<NP> &
     }
 }
 
-// Ln - m on active lanes (m: wave-uniform minimum); idle lanes keep the sentinel
+// Ln - m on active lanes (ms = {m, m}, m the wave-uniform minimum); idle lanes keep the sentinel
 template <int NP, bool PARTIAL>
-__device__ __forceinline__ void path_normalise(const Pack<NP> &Ln, uint32_t m, bool active, Pack<NP> &out)
+__device__ __forceinline__ void path_normalise_splat(const Pack<NP> &Ln, uint32_t ms, bool active, Pack<NP> &out)
 {
-    const uint32_t ms = splat16(m);
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         uint32_t v = pk_sub(Ln.r[i], ms);
         if (PARTIAL) v = active ? v : SGM_SENT;
         out.r[i] = v;
     }
+}
+template <int NP, bool PARTIAL>
+__device__ __forceinline__ void path_normalise(const Pack<NP> &Ln, uint32_t m, bool active, Pack<NP> &out)
+{
+    path_normalise_splat<NP, PARTIAL>(Ln, splat16(m), active, out);
 }
 
 // Winner-take-all on the finished S of one pixel (A.6 steps 1-2; steps 3-4 run in k_select).
@@ -365,9 +369,9 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
         Pack<NP> Ln, Lnorm;
         uint32_t rmin;
         path_elem<NP, PARTIAL>(cv, L, P1s, P2s, active, Ln, rmin, sr);
-        const uint32_t mL = halves_min(wave_min_pk(rmin));
-        hm = max(hm, mL);
-        path_normalise<NP, PARTIAL>(Ln, mL, active, Lnorm);
+        const uint32_t mLs = wave_min1_splat(rmin);
+        hm = max(hm, mLs & 0xffffu);
+        path_normalise_splat<NP, PARTIAL>(Ln, mLs, active, Lnorm);
         if (MODE == PATH_BOUNDARY) {
             // state of the last row of a band, consumed by the first row of the next band
             if (to_boundary == 0) {
@@ -561,19 +565,17 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
 
     // rows s with (s + 1) % R == 0 end a band: their state goes to the record of band (s + 1) / R
     int to_boundary = R - 1 - s_begin % R, next_band = s_begin / R + 1;
-    uint32_t hm_hi = 0, hm_lo = 0;
+    uint32_t hm = 0;
     auto one_step = [&](Pack<NP> *c3, bool store_ok) {
         Pack<NP> N[3];
         uint32_t r[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) path_elem<NP, PARTIAL>(c3[d], L[d], P1s, P2s, active, N[d], r[d], sr[d]);
-        const uint32_t m01 = wave_min_pk(pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])));
-        const uint32_t m2 = halves_min(wave_min_pk(r[2]));
-        hm_hi = max(hm_hi, m01);  // headroom record (see k_sweep; this kernel is bound by memory, not by issue)
-        hm_lo = max(hm_lo, max(m01 & 0xffffu, m2));
-        path_normalise<NP, PARTIAL>(N[0], m01 & 0xffffu, active, L[0]);
-        path_normalise<NP, PARTIAL>(N[1], m01 >> 16, active, L[1]);
-        path_normalise<NP, PARTIAL>(N[2], m2, active, L[2]);
+        uint32_t ms[3];
+        wave_min3_splat(r[0], r[1], r[2], ms);
+        hm = max(hm, max(ms[0], max(ms[1], ms[2])));  // headroom record (splats: see k_sweep)
+#pragma unroll
+        for (int d = 0; d < 3; d++) path_normalise_splat<NP, PARTIAL>(N[d], ms[d], active, L[d]);
         if (to_boundary == 0) {
             if (store_ok && active) {
 #pragma unroll
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
 #pragma unroll
         for (int d = 0; d < 3; d++) L[d].store(state_out + ((int64_t)d * W1 + xc[d]) * D + lane_off);
     }
-    if (g.hr && lane == 0) atomicMax(g.hr + 1, max(hm_hi >> 16, hm_lo));
+    if (g.hr && lane == 0) atomicMax(g.hr + 1, hm & 0xffffu);
 }
 
 }  // namespace sgm

@@ -254,10 +254,9 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     L0.fill(init);
     ShiftRegs sr0, srA, srB, srC;
     // headroom record (sgm_get_headroom): largest min_d L_r(p, d) of the row, all four directions.
-    // The reductions return {min of one direction, min of another} packed; an unsigned 32-bit
-    // maximum of such pairs keeps the largest HIGH half exactly, the low halves take their own
-    // maximum -- scalar instructions only, nothing added to the vector stream.
-    uint32_t hm_hi = 0, hm_lo = 0;
+    // The reductions return splats {m, m}, whose unsigned 32-bit maximum is the splat of the
+    // maximum -- four scalar instructions per pixel, nothing added to the vector stream.
+    uint32_t hm = 0;
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
     // this row of C and S as buffer resources: one constant per-lane byte offset register plus a
     // scalar byte offset per pixel (b0 + k * bk), so no address VGPRs alias the load destinations
@@ -298,17 +297,17 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
         path_elem<NP, PARTIAL>(Cp, QA, P1s, P2s, active, NA, rA, srA);
         path_elem<NP, PARTIAL>(Cp, QB, P1s, P2s, active, NB, rB, srB);
         path_elem<NP, PARTIAL>(Cp, QC, P1s, P2s, active, NC, rC, srC);
-        const uint32_t m0A = wave_min_pk(pk_min_s(pack_lo(r0, rA), pack_hi(r0, rA)));  // {min 0, min A}
-        const uint32_t mBC = wave_min_pk(pk_min_s(pack_lo(rB, rC), pack_hi(rB, rC)));  // {min B, min C}
-        smax_u32(hm_hi, m0A);
-        smax_u32(hm_hi, mBC);
-        smax_u32(hm_lo, m0A & 0xffffu);
-        smax_u32(hm_lo, mBC & 0xffffu);
+        uint32_t ms[4];  // {m, m} of the directions 0, A, B, C
+        wave_min4_splat(r0, rA, rB, rC, ms);
+        smax_u32(hm, ms[0]);
+        smax_u32(hm, ms[1]);
+        smax_u32(hm, ms[2]);
+        smax_u32(hm, ms[3]);
         Pack<NP> LA, LB, LC;
-        path_normalise<NP, PARTIAL>(N0, m0A & 0xffffu, active, L0);
-        path_normalise<NP, PARTIAL>(NA, m0A >> 16, active, LA);
-        path_normalise<NP, PARTIAL>(NB, mBC & 0xffffu, active, LB);
-        path_normalise<NP, PARTIAL>(NC, mBC >> 16, active, LC);
+        path_normalise_splat<NP, PARTIAL>(N0, ms[0], active, L0);
+        path_normalise_splat<NP, PARTIAL>(NA, ms[1], active, LA);
+        path_normalise_splat<NP, PARTIAL>(NB, ms[2], active, LB);
+        path_normalise_splat<NP, PARTIAL>(NC, ms[3], active, LC);
         uint32_t *s = mine + u * SLOT;
         lds_store<NP>(LA, s + 0 * ROLE);
         lds_store<NP>(LB, s + 1 * ROLE);
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
             compute_block_t(part, cB, sB, k0 + PB);
         }
     }
-    if (g.hr && lane == 0) atomicMax(g.hr + 1, max(hm_hi >> 16, hm_lo));
+    if (g.hr && lane == 0) atomicMax(g.hr + 1, hm & 0xffffu);
     // one step after the last real pixel: the virtual pixel W1 (start state) for the row below
     if (wave < R - 1) {
         write_start_state(mine, W1 % RING);

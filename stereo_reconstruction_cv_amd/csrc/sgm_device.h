@@ -82,6 +82,63 @@ __device__ __forceinline__ uint32_t halves_min(uint32_t pk) { return min(pk & 0x
 __device__ __forceinline__ uint32_t pack_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
 __device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
+// ---- minima of several directions at once, returned SPLAT ({m, m}) in SGPRs ------------------------
+// Operands: per-lane packed partial minima of values in [0, 0x7fff] (inside the int16 regime every
+// path cost is; outside it hr[0] of the headroom record says so whatever these return).  Once both
+// halves of a dword are equal, the unsigned 32-bit order of such dwords is the order of the value, so
+// a butterfly step is ONE v_min_u32 with a DPP operand instead of v_mov_b32_dpp + v_pk_min_i16.
+// gfx950's half / row swaps (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the
+// second; v_permlane16_swap: odd rows of the first <-> even rows of the second) fold four independent
+// reductions into one register in three steps: 12 vector instructions + 4 v_readlane for the four
+// directions of a sweep pixel (before: 2 perm-packs of 3, two packed butterflies of 12, 2 readlanes and
+// the scalar unpack / splat), and the result is the splat the normalisation subtracts.
+__device__ __forceinline__ uint32_t fold_halves(uint32_t x) { return pk_min_s(x, __builtin_amdgcn_alignbit(x, x, 16)); }
+// minimum over each row of 16 lanes, left in every lane of the row (equal-halves dwords)
+__device__ __forceinline__ uint32_t row_min_eq(uint32_t x)
+{
+    x = min(x, dpp_view<DPP_QUAD_1032>(x));
+    x = min(x, dpp_view<DPP_QUAD_2301>(x));
+    x = min(x, dpp_view<DPP_ROW_HALF_MIRROR>(x));
+    x = min(x, dpp_view<DPP_ROW_MIRROR>(x));
+    return x;
+}
+// lanes 0-31: min over the wave of a, lanes 32-63: of b (per lane pair l, l + 32)
+__device__ __forceinline__ uint32_t fold32_pair(uint32_t a, uint32_t b)
+{
+    const auto s = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return pk_min_s(s[0], s[1]);
+}
+// rows 0 / 2: rows 0-1 / 2-3 of a folded, rows 1 / 3: rows 0-1 / 2-3 of b folded
+__device__ __forceinline__ uint32_t fold16_pair(uint32_t a, uint32_t b)
+{
+    const auto s = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    return pk_min_s(s[0], s[1]);
+}
+__device__ __forceinline__ void wave_min4_splat(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t (&ms)[4])
+{
+    // rows of 16 lanes after the two folds: directions 0, 2, 1, 3
+    const uint32_t x = row_min_eq(fold_halves(fold16_pair(fold32_pair(r0, r1), fold32_pair(r2, r3))));
+    ms[0] = __builtin_amdgcn_readlane(x, 0);
+    ms[2] = __builtin_amdgcn_readlane(x, 16);
+    ms[1] = __builtin_amdgcn_readlane(x, 32);
+    ms[3] = __builtin_amdgcn_readlane(x, 48);
+}
+__device__ __forceinline__ void wave_min3_splat(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t (&ms)[3])
+{
+    // rows: direction 0, rows 0-1 of direction 2, direction 1, rows 2-3 of direction 2
+    const uint32_t x = row_min_eq(fold_halves(fold16_pair(fold32_pair(r0, r1), r2)));
+    ms[0] = __builtin_amdgcn_readlane(x, 0);
+    ms[1] = __builtin_amdgcn_readlane(x, 32);
+    ms[2] = min(__builtin_amdgcn_readlane(x, 16), __builtin_amdgcn_readlane(x, 48));
+}
+__device__ __forceinline__ uint32_t wave_min1_splat(uint32_t r)
+{
+    uint32_t x = row_min_eq(fold_halves(r));
+    x = min(x, dpp_view<DPP_ROW_BCAST15, 0xa>(x));
+    x = min(x, dpp_view<DPP_ROW_BCAST31, 0xc>(x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 // min over the 64 lanes of an unsigned 32-bit value; result is wave-uniform (SGPR)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
 {
