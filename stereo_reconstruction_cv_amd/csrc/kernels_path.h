@@ -463,7 +463,8 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
 // loads in flight (counted vmcnt).  The rare iterations with a wrap take the per-step path.
 // Byte offsets are 32-bit (the host checks volume bytes < 2^31).
 template <int NP, bool PARTIAL>
-__global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 4 : 2)))
+void k_prepass3(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
                                                  int16_t *__restrict__ bndL, int R, int s_begin, int s_end,
                                                  const int16_t *__restrict__ state_in, int16_t *__restrict__ state_out,
                                                  int cpx)
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
 
     // rows s with (s + 1) % R == 0 end a band: their state goes to the record of band (s + 1) / R
     int to_boundary = R - 1 - s_begin % R, next_band = s_begin / R + 1;
+    const int bnd_row = W1 * 3 * D;  // int16 elements of one band's record
     uint32_t hm = 0;
     auto one_step = [&](Pack<NP> *c3, bool store_ok) {
         Pack<NP> N[3];
@@ -577,10 +579,14 @@ __global__ __launch_bounds__(64) void k_prepass3(Geom g, int xdir, int ydir, con
 #pragma unroll
         for (int d = 0; d < 3; d++) path_normalise_splat<NP, PARTIAL>(N[d], ms[d], active, L[d]);
         if (to_boundary == 0) {
-            if (store_ok && active) {
+            if (store_ok) {
+                // the band's record [x][3][D] as a buffer resource: scalar address arithmetic only, no
+                // 64-bit per-lane pointers (they cost the registers that decide 4 or 3 waves per SIMD)
+                const __amdgpu_buffer_rsrc_t brec = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(bndL + (int64_t)next_band * bnd_row), 0, (int)((uint32_t)bnd_row * 2u), 0x00020000);
 #pragma unroll
                 for (int d = 0; d < 3; d++)
-                    L[d].store(bndL + (((int64_t)next_band * W1 + xc[d]) * 3 + d) * D + lane_off);
+                    if (!PARTIAL || active) buf_store<NP>(L[d], brec, voff, (xc[d] * 3 + d) * D * 2);
             }
             to_boundary = R;
             next_band++;
