@@ -87,7 +87,7 @@ typedef enum {
     SGM_OPT_PROFILE = 1,     /* 1: bracket every stage with HIP events on the engine's stream    */
     SGM_OPT_SCHEDULE = 2,    /* 0: one kernel per path direction; 1 (default): fused 4-direction sweeps */
     SGM_OPT_SWEEP_ROWS = 3,  /* rows per band of the fused sweep; 0 = automatic                  */
-    SGM_OPT_PREPASS_ROWS = 5, /* rows per chunk (= launch) of the boundary pre-pass; 0 = automatic (about 270) */
+    SGM_OPT_PREPASS_ROWS = 5, /* rows per chunk (= launch) of the boundary pre-pass; 0 = automatic (about 135, a multiple of 8) */
     SGM_OPT_DEBUG = 4        /* A/B switches for measurements, a bit mask.  Results stay correct except
                               * for bit 64.   2: winner-take-all fused into the last path kernel
                               * everywhere;  4: no lane groups for D <= 64;  8: narrow vertical box
@@ -99,7 +99,9 @@ typedef enum {
                               * with the plain line-per-block layout (no XCD grouping);  2048: winner-take-all
                               * always as its own pass;  4096: D <= 64 with the three-role grouped pre-pass and
                               * the four-direction row kernel (round 1) instead of per-role pre-pass + element-wise
-                              * vertical kernel + in-row kernel;  8192: that small-D schedule for D <= 32 only */
+                              * vertical kernel + in-row kernel;  8192: that small-D schedule for D <= 32 only;
+                              * 16384: D = 256, the upward pre-pass (the one beside the sweep) with prefetch
+                              * blocks of 2 rows (70 registers instead of 106) */
 } sgm_option;
 
 #define SGM_MAX_STAGES 32

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
             compute_slow(cB, sB, s0 + PB);
         }
     }
-    if (g.hr && lane == 0) atomicMax(g.hr + 1, hm);
+    if (g.hr && lane == 0) headroom_raise(g.hr + 1, hm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -462,23 +462,30 @@ __global__ __launch_bounds__(64) void k_path(Geom g, int rx, int ry, const int16
 // in which no diagonal leaves the image is straight-line code, so hipcc keeps the next block's
 // loads in flight (counted vmcnt).  The rare iterations with a wrap take the per-step path.
 // Byte offsets are 32-bit (the host checks volume bytes < 2^31).
-template <int NP, bool PARTIAL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 4 : 2)))
+#ifndef SGM_PREPASS_WPB
+#define SGM_PREPASS_WPB 4  // waves (adjacent base columns) per workgroup: a quarter of the workgroups to dispatch per chunk
+#endif
+template <int NP, bool PARTIAL, int PB = SGM_PREPASS_PB>
+__global__ __launch_bounds__(64 * SGM_PREPASS_WPB) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? (PB <= 2 ? 5 : 4) : 2)))
 void k_prepass3(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
                                                  int16_t *__restrict__ bndL, int R, int s_begin, int s_end,
                                                  const int16_t *__restrict__ state_in, int16_t *__restrict__ state_out,
                                                  int cpx)
 {
-    constexpr int PB = SGM_PREPASS_PB;  // rows per prefetch block: 2 blocks x 3 roles in registers keeps 4 waves per SIMD
-    const int lane = threadIdx.x;
+    // PB = rows per prefetch block: 2 blocks x 3 roles in registers.  PB = 4 keeps 4 waves per SIMD (a
+    // pre-pass that has the GPU to itself); PB = 2 fits under 96 registers for the pass that shares the
+    // SIMDs with the sweep's waves (its occupancy there is decided by what those leave over).
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int W1 = g.W1, D = g.D, H = g.H;
     // base column of this wave: XCD-group layout (cpx > 0) or the plain one
-    int base = blockIdx.x;
+    int base = blockIdx.x * SGM_PREPASS_WPB + wave;
     if (cpx > 0) {
-        const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int grp = blockIdx.x & 7, slot = (blockIdx.x >> 3) * SGM_PREPASS_WPB + wave;
         base = grp * cpx + slot;
-        if (slot >= cpx || base >= W1) return;
+        if (slot >= cpx) return;
     }
+    if (base >= W1) return;
     const bool active = !PARTIAL || (2 * NP * lane < D);
     const int lane_off = active ? 2 * NP * lane : 0;
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
@@ -623,12 +630,21 @@ void k_prepass3(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
     for (int s0 = s_begin; s0 < s_end; s0 += 2 * PB) {
         const bool fast = s0 + 3 * PB <= s_end && stays(xl[0], 0, 2 * PB) && stays(xl[2], 2, 2 * PB) &&
                           stays(xc[0], 0, 2 * PB) && stays(xc[2], 2, 2 * PB);
+        // the chunk's last two blocks (chunk heights are multiples of 2 * PB wherever H allows): the same
+        // straight-line code without the second load -- a chunk ends without a drained pipeline
+        const bool last = s0 + 2 * PB == s_end && stays(xl[0], 0, PB) && stays(xl[2], 2, PB) &&
+                          stays(xc[0], 0, 2 * PB) && stays(xc[2], 2, 2 * PB);
         if (fast) {
             load_fast(cB);
             compute_fast(cA, s0);
             load_fast(cA);
             compute_fast(cB, s0 + PB);
             wrap_load();      // a cursor may stand exactly one past the border now
+            wrap_compute();
+        } else if (last) {
+            load_fast(cB);
+            compute_fast(cA, s0);
+            compute_fast(cB, s0 + PB);
             wrap_compute();
         } else {
             load_slow(cB, s0 + PB);
@@ -642,7 +658,7 @@ void k_prepass3(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
 #pragma unroll
         for (int d = 0; d < 3; d++) L[d].store(state_out + ((int64_t)d * W1 + xc[d]) * D + lane_off);
     }
-    if (g.hr && lane == 0) atomicMax(g.hr + 1, hm & 0xffffu);
+    if (g.hr && lane == 0) headroom_raise(g.hr + 1, hm & 0xffffu);
 }
 
 }  // namespace sgm

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
             compute_block_t(part, cB, sB, k0 + PB);
         }
     }
-    if (g.hr && lane == 0) atomicMax(g.hr + 1, hm & 0xffffu);
+    if (g.hr && lane == 0) headroom_raise(g.hr + 1, hm & 0xffffu);
     // one step after the last real pixel: the virtual pixel W1 (start state) for the row below
     if (wave < R - 1) {
         write_start_state(mine, W1 % RING);

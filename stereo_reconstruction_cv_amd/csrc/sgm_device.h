@@ -165,10 +165,19 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
 // Headroom record of one compute (sgm_get_headroom): hr[0] = max of C_true (incl. the running-sum
 // intermediate C(y-1) + hsum(y+r) upstream holds in an int16 lane), hr[1] = max over pixels and
 // directions of min_d L_r(p, d).  `v` holds per-lane packed uint16 maxima; one atomic per wave.
+// One wave's contribution to a headroom maximum (call from ONE lane).  Thousands of waves end a kernel
+// with an atomic on the same address; same-address atomics are serialised at the memory side
+// (MI355X_MICROARCH.md: "every workgroup into ONE row: 14x slower") -- 3584 of them kept a pre-pass chunk
+// of 8 rows alive for 45 us.  The record only grows, so a plain read first is safe in both directions
+// (a stale, smaller value merely costs the atomic), and after the first few waves nearly all skip it.
+__device__ __forceinline__ void headroom_raise(uint32_t *p, uint32_t m)
+{
+    if (m > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, m);
+}
 __device__ __forceinline__ void headroom_commit_pk(uint32_t *hr, int slot, uint32_t v)
 {
     const uint32_t m = wave_max_u32(max(v & 0xffffu, v >> 16));
-    if (hr && lane_id() == 0) atomicMax(hr + slot, m);
+    if (hr && lane_id() == 0) headroom_raise(hr + slot, m);
 }
 
 // acc = max(acc, x) on the scalar unit (both wave-uniform).  Written as asm: left to the compiler a chain

@@ -85,7 +85,7 @@ struct sgm_engine {
     int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps
     int sweep_rows = 0;  // rows per band of the sweep (0 = automatic)
     int debug = 0;       // timing experiments (SweepArgs::dbg)
-    int prepass_rows = 0;  // rows per chunk of the boundary pre-pass (0 = automatic, about 270)
+    int prepass_rows = 0;  // rows per chunk of the boundary pre-pass (0 = automatic, about 135, a multiple of 8)
     sgm_engine *peer = nullptr;  // second engine (own stream and buffers) for two pairs in flight in sgm_compute_batch
 
     // shape of the last compute
@@ -592,16 +592,22 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 const int cpx = plain ? 0 : (g.W1 + 7) / 8;
                 // (Padding the grid so that every SIMD holds the same number of waves, and halving the
                 // prefetch depth, were both measured: no change -- DESIGN.md 4.4.)
-                dim3 grid(plain ? g.W1 : 8 * cpx), block(64);
+                const int wpb = SGM_PREPASS_WPB;
+                dim3 grid(plain ? (g.W1 + wpb - 1) / wpb : 8 * ((cpx + wpb - 1) / wpb)), block(64 * wpb);
                 const size_t half = (size_t)3 * g.W1 * g.D;  // int16 elements of one state buffer
                 int16_t *sbuf = (int16_t *)(ydir > 0 ? e->pstate.p : e->pstate2.p);
                 const int16_t *sin = sbuf ? sbuf + (size_t)(c & 1) * half : nullptr;
                 int16_t *sout = sbuf ? sbuf + (size_t)((c + 1) & 1) * half : nullptr;
 #define SGM_PRE(NP_, PART_) hipLaunchKernelGGL((k_prepass3<NP_, PART_>), grid, block, 0, on, g, xdir, ydir, C, bl, R, s0, s1, sin, sout, cpx)
+#define SGM_PRE2(NP_, PART_) hipLaunchKernelGGL((k_prepass3<NP_, PART_, 2>), grid, block, 0, on, g, xdir, ydir, C, bl, R, s0, s1, sin, sout, cpx)
+                // debug 16384: short prefetch blocks (fewer registers) for the pass that runs beside the sweep
+                const bool shortpb = g.NP == 2 && (e->debug & 16384) && on != st;
                 if (g.NP == 1) { if (partial) SGM_PRE(1, true); else SGM_PRE(1, false); }
+                else if (shortpb) { if (partial) SGM_PRE2(2, true); else SGM_PRE2(2, false); }
                 else if (g.NP == 2) { if (partial) SGM_PRE(2, true); else SGM_PRE(2, false); }
                 else { if (partial) SGM_PRE(4, true); else SGM_PRE(4, false); }
 #undef SGM_PRE
+#undef SGM_PRE2
             };
             // roles of the pre-pass: 0 = predecessor one step earlier in the sweep's x order
             // (x - xdir), 1 = same column, 2 = one step later
@@ -624,12 +630,13 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 }
                 if (fused_prepass) {
                     // the three roles fused in one wave (k_prepass3); debug bit 16 selects the 3-launch variant.
-                    // Row chunks of about 270 rows, one launch each, base columns grouped per XCD: two of the
+                    // Row chunks of about 135 rows, one launch each, base columns grouped per XCD: two of the
                     // three reads of a C pixel hit L2 (kernels_path.h).  debug 512: one chunk, plain layout (A/B).
                     const bool plain = (e->debug & 512) != 0;
                     const int nch = plain ? 1 : (e->prepass_rows > 0 ? (H + e->prepass_rows - 1) / e->prepass_rows
-                                                                          : std::max(1, (H + 135) / 270));
-                    const int Hc = (H + nch - 1) / nch;
+                                                                          : std::max(1, (H + 67) / 135));
+                    // multiples of 8 rows (two prefetch blocks): a chunk then ends in straight-line code
+                    const int Hc = e->prepass_rows > 0 ? e->prepass_rows : ((H + nch - 1) / nch + 7) / 8 * 8;
                     int n = 0;
                     for (int c = 0; c < nch; c++) {
                         const int s0 = c * Hc, s1 = std::min(H, s0 + Hc);
