@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--schedule", type=int, default=1, help="0: one kernel per path direction, 1: fused sweeps")
     ap.add_argument("--debug", type=int, default=0, help="SGM_OPT_DEBUG bit mask (A/B measurements; include/sgm_hip.h)")
     ap.add_argument("--prepass-rows", type=int, default=0, help="rows per chunk of the boundary pre-pass (0 = automatic)")
+    ap.add_argument("--sweep-rows", type=int, default=0, help="rows per band of the fused sweeps (0 = automatic)")
     args = ap.parse_args()
 
     # ---- N > 1 without a launcher: become the parent of N ranks (before torch / HIP are imported)
@@ -276,6 +277,8 @@ def main():
             e.set_option(_lib.SGM_OPT_DEBUG, args.debug)
         if not mock and args.prepass_rows:
             e.set_option(_lib.SGM_OPT_PREPASS_ROWS, args.prepass_rows)
+        if not mock and args.sweep_rows:
+            e.set_option(_lib.SGM_OPT_SWEEP_ROWS, args.sweep_rows)
         engines.append(e)
     eng = engines[0]
 

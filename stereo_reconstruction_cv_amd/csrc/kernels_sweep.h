@@ -39,7 +39,7 @@ struct SweepArgs {
     int band0;  // the launch covers bands band0 .. band0 + gridDim.x - 1 (row-chunk pipelining of the first pass)
 };
 
-constexpr int SWEEP_MAX_ROWS = 9;  // compute waves per workgroup (640 threads -> 168 VGPRs per lane)
+constexpr int SWEEP_MAX_ROWS = 11;  // compute waves per workgroup (768 threads = 3 waves per SIMD -> 168 VGPRs per lane)
 // pixels a wave advances per lockstep step (one barrier per step): two give the scheduler two
 // independent dependency chains per wave and halve the barrier / LDS round trips per pixel
 __host__ __device__ constexpr int sweep_pps(int NP) { return NP == 4 ? 1 : (NP == 1 ? 4 : 2); }

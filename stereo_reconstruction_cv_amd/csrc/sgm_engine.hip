@@ -295,12 +295,16 @@ static int launch_sweep(const Geom &g, const SweepArgs &a, int mode, int nbands,
 }
 
 // rows per band: about 240 bands (one workgroup per CU, most of the 256 CUs busy), bounded by
-// SWEEP_MAX_ROWS (register budget of the workgroup) and the 160 KiB of LDS
-static int sweep_rows_for(const Geom &g, int override_rows)
+// SWEEP_MAX_ROWS (register budget of the workgroup) and the 160 KiB of LDS.  MODE_HH: about 200 bands --
+// a band's step time is set by its busiest SIMD (3 waves with 9 rows + loader as with 11 + loader), so
+// taller bands cost the sweep nothing, write and read 18 % less boundary state and leave more CUs to the
+// upward pre-pass that runs beside the downward sweep (4K: 11.05 -> 10.9 ms; MODE_SGBM: no gain).
+static int sweep_rows_for(const Geom &g, int override_rows, int npass)
 {
     int maxR = SWEEP_MAX_ROWS;
     while (maxR > 1 && sweep_lds_bytes(g.NP, maxR) > 160 * 1024) maxR--;
-    int R = override_rows > 0 ? override_rows : (g.H + 239) / 240;
+    const int bands = npass == 2 ? 200 : 240;
+    int R = override_rows > 0 ? override_rows : (g.H + bands - 1) / bands;
     if (override_rows <= 0) R = std::max(R, 4);
     return std::max(1, std::min(R, maxR));
 }
@@ -497,9 +501,9 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // debug 8192: D <= 32 only (the round-1 limit; A/B)
         const bool rows4 = GWs <= ((e->debug & 8192) ? 16 : 32) && e->sweep_rows <= 0 &&
                            (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
-        const int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows);
-        const int nbands = (H + R - 1) / R;
         const int npass = g.mode == 1 ? 2 : 1;
+        const int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows, npass);
+        const int nbands = (H + R - 1) / R;
         // Narrow frames (fewer than ~1.5 lines per SIMD) are bound by the latency of one wave's
         // instruction stream: there the single-direction kernel with one wave per (line, role) -- three
         // times the waves, a third of the work each -- is faster (720p D=64: 0.26 against 0.34 ms); its

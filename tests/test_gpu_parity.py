@@ -54,7 +54,7 @@ def test_every_stage_bit_exact_per_direction_schedule(H, W, D, bs, minD, mode, s
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("rows", [1, 2, 3, 5, 9])
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 9, 10, 11])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_sweep_band_heights(rows, mode):
     """band height of the fused sweep must not matter (boundary pre-pass + LDS hand-off)"""

@@ -53,7 +53,7 @@ def test_debug_switches_keep_results(debug, H, W, D, bs, mode):
         assert U.headroom_equal(h, t), (dbg, h["headroom"], t["max_cost_plus_p2"], t["max_delta"])
 
 
-@pytest.mark.parametrize("chunk", [1, 2, 5, 7, 16, 64])
+@pytest.mark.parametrize("chunk", [1, 2, 5, 7, 8, 16, 24, 64])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_prepass_row_chunks(chunk, mode):
     """The boundary pre-pass walks the image in row chunks (one launch each) and hands the state of
@@ -69,6 +69,22 @@ def test_prepass_row_chunks(chunk, mode):
         assert t["headroom_ok"]
         bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
         assert not bad, f"chunk={chunk} {(H, W, D)}: " + "\n".join(bad)
+
+
+@pytest.mark.parametrize("chunk", [4, 8, 12, 40])
+def test_upward_prepass_with_short_prefetch_blocks(chunk):
+    """debug 16384: the pre-pass that shares the GPU with the downward sweep (MODE_HH, auxiliary stream)
+    runs the k_prepass3 instantiation with prefetch blocks of 2 rows; chunk heights that are and are
+    not multiples of its iteration (4 rows), full and partial wavefronts (D = 256 / 192)."""
+    for (H, W, D, bs, seed) in ((53, 420, 256, 7, 81), (44, 330, 192, 5, 82)):
+        l, r, _ = synth.make_pair(H, W, D, seed)
+        p = U.params(D, bs, 0, 1, speckleWindowSize=30, speckleRange=2)
+        want, t = O.sgbm_compute(l, r, taps=True, **p)
+        assert t["headroom_ok"]
+        h = U.run_hip_with_taps(l, r, p, schedule=1, sweep_rows=3, debug=16384, prepass_rows=chunk)
+        assert np.array_equal(h["S"], t["S"]), U.describe_mismatch("S", h["S"], t["S"])
+        assert np.array_equal(h["disp"], want)
+        assert U.headroom_equal(h, t)
 
 
 def test_headroom_record_at_the_edge_of_the_regime():
