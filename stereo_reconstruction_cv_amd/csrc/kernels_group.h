@@ -78,10 +78,8 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
         uint32_t rmin;
         path_inner_min<NP, PARTIAL, GW>(U, P1s, t, sr, ge);
         path_finish<NP, PARTIAL>(cv, t, ms, P2s, active, Un, rmin);
-        const uint32_t m = group_min_pk<GW>(rmin);
-        const uint32_t mL = min(m & 0xffffu, m >> 16);
-        hm = max(hm, mL);
-        ms = splat16(mL);
+        ms = group_min_splat<GW>(rmin);
+        hm = max(hm, ms);  // (splats: the unsigned maximum of splats is the splat of the maximum)
         if (PARTIAL && !active) ms = 0;  // (idle lanes: keep their sentinel arithmetic away from wrap-around)
         Pack<NP> Sn;
 #pragma unroll
@@ -207,10 +205,9 @@ __global__ __launch_bounds__(64) void k_rows4_g(Geom g, int xdir, int ydir, cons
         path_elem<NP, true, GW>(p.c, QA, P1s, P2s, active, NA, rA, srA, ge);
         path_elem<NP, true, GW>(p.c, QB, P1s, P2s, active, NB, rB, srB, ge);
         path_elem<NP, true, GW>(p.c, QC, P1s, P2s, active, NC, rC, srC, ge);
-        const uint32_t m = group_min_pk<GW>(r0);
-        const uint32_t mL = min(m & 0xffffu, m >> 16);
-        hm = max(hm, mL);  // (the three other directions are recorded by k_prepass3_g)
-        path_normalise<NP, true>(N0, mL, active, Ln);
+        const uint32_t m0s = group_min_splat<GW>(r0);
+        hm = max(hm, m0s & 0xffffu);  // (the three other directions are recorded by k_prepass3_g)
+        path_normalise_splat<NP, true>(N0, m0s, active, Ln);
         L0 = Ln;
         Pack<NP> Sn;
         uint32_t v = pk_adds_s(pk_adds_s(N0.r[0], NA.r[0]), pk_adds_s(NB.r[0], NC.r[0]));
@@ -306,10 +303,9 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
 #pragma unroll
         for (int d = 0; d < NR; d++) path_elem<NP, true, GW>(cv[u][d], L[d], P1s, P2s, active, N[d], r[d], sr[d], ge);
         if constexpr (SPLIT) {
-            const uint32_t mm = group_min_pk<GW>(r[0]);
-            const uint32_t m0 = min(mm & 0xffffu, mm >> 16);
-            if (s < H) hm = max(hm, m0);
-            path_normalise<NP, true>(N[0], m0, active, L[0]);
+            const uint32_t m0s = group_min_splat<GW>(r[0]);
+            if (s < H) hm = max(hm, m0s & 0xffffu);
+            path_normalise_splat<NP, true>(N[0], m0s, active, L[0]);
         } else {
             uint32_t mm[2] = {pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])), r[2]};
             group_min_pk_n<GW, 2>(mm);

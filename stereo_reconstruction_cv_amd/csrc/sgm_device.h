@@ -275,6 +275,29 @@ template <int GW> __device__ __forceinline__ uint32_t group_min_pk(uint32_t x)
     return a[0];
 }
 
+// One direction's minimum over a lane group, returned as the splat {m, m} in every lane of the group
+// (GW = 64: wave-uniform).  Halves folded first, then one v_min_u32 with a DPP operand per butterfly step:
+// 2 + log2(GW) dependent instructions instead of 2 * log2(GW) + the scalar halves-minimum and splat --
+// the in-row kernels are bound by exactly this chain.  Operands in [0, 0x7fff] (see wave_min4_splat).
+template <int GW> __device__ __forceinline__ uint32_t group_min_splat(uint32_t r)
+{
+    if constexpr (GW == 64) {
+        return wave_min1_splat(r);
+    } else {
+        uint32_t x = fold_halves(r);
+        x = min(x, dpp_view<DPP_QUAD_1032>(x));
+        x = min(x, dpp_view<DPP_QUAD_2301>(x));
+        x = min(x, dpp_view<DPP_ROW_HALF_MIRROR>(x));  // 8 lanes done
+        if constexpr (GW >= 16) x = min(x, dpp_view<DPP_ROW_MIRROR>(x));
+        if constexpr (GW == 32) {
+            x = min(x, dpp_view<DPP_ROW_BCAST15, 0xa>(x));  // lanes 31 / 63: minimum of rows 0-1 / 2-3
+            const uint32_t a = __builtin_amdgcn_readlane(x, 31), b = __builtin_amdgcn_readlane(x, 63);
+            x = lane_id() < 32 ? a : b;
+        }
+        return x;
+    }
+}
+
 // NP packed registers per lane, moved as one vector access
 template <int NP> struct PackVec;
 template <> struct PackVec<1> { typedef uint32_t type; };
