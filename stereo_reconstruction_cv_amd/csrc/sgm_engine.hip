@@ -73,6 +73,31 @@ struct DevBuf {
     }
 };
 
+// page-locked host memory (staging of sgm_compute_batch): copies to / from it are truly asynchronous
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SGM_OK;
+        release();
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_err(SGM_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return SGM_ERR_NOMEM;
+        }
+        cap = bytes;
+        return SGM_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct sgm_engine {
     sgm_params params;
     int device = 0;
@@ -86,7 +111,11 @@ struct sgm_engine {
     int sweep_rows = 0;  // rows per band of the sweep (0 = automatic)
     int debug = 0;       // timing experiments (SweepArgs::dbg)
     int prepass_rows = 0;  // rows per chunk of the boundary pre-pass (0 = automatic, about 135, a multiple of 8)
-    sgm_engine *peer = nullptr;  // second engine (own stream and buffers) for two pairs in flight in sgm_compute_batch
+    // sgm_compute_batch: up to three pairs in flight = this engine + two peers (own stream and device
+    // buffers), each with page-locked staging buffers for the images and the disparity map
+    sgm_engine *peer = nullptr, *peer2 = nullptr;
+    HostBuf pin_left, pin_right, pin_disp;
+    hipEvent_t ev_done = nullptr;
 
     // shape of the last compute
     int H = 0, W = 0;
@@ -916,7 +945,12 @@ void sgm_destroy(sgm_engine *e)
         (void)hipStreamDestroy(e->aux);
     }
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    e->pin_left.release();
+    e->pin_right.release();
+    e->pin_disp.release();
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->peer) sgm_destroy(e->peer);
+    if (e->peer2) sgm_destroy(e->peer2);
     delete e;
 }
 
@@ -1137,10 +1171,14 @@ int sgm_compute(sgm_engine *e, const uint8_t *left, const uint8_t *right, int H,
     return SGM_OK;
 }
 
-// N independent pairs from / to host memory.  Two pairs are in flight: pair i runs on engine i % 2
-// (the engine itself and a peer with its own stream and device buffers, created on first use), so
-// the host-side copies of one pair overlap the kernels of the other and the second pair fills the
-// SIMD slots a single frame leaves idle.
+// N independent pairs from / to host memory.  Up to three pairs are in flight: pair i runs on engine
+// i % 3 (the engine itself and two peers with their own streams and device buffers, created on first
+// use).  Images and disparity maps are staged through page-locked buffers of the engine they run on, so
+// every transfer is asynchronous: while the host copies the results of pair i - 3 out of, and pair i
+// into, the staging buffers of one engine, the other two keep the GPU busy with two frames (a second
+// frame fills the issue slots and the HBM time one frame leaves idle).  The XYZ image
+// (99.5 MB per 4K pair) goes straight to the caller's buffer: staging it would cost the host more than
+// the pageable copy does.
 int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t *rights, int H, int W,
                       int16_t *disps_out, float *xyz_out, const double *Q16)
 {
@@ -1150,11 +1188,11 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
     HIP_TRY(hipSetDevice(e->device));
     const size_t npx = (size_t)H * W;
     int rc;
-    if (N > 1 && !e->peer) {
-        if ((rc = sgm_create(&e->params, e->device, nullptr, &e->peer))) return rc;
-    }
-    sgm_engine *eng[2] = {e, (N > 1) ? e->peer : e};
-    for (int k = 0; k < (N > 1 ? 2 : 1); k++) {
+    const int neng = std::min(N, 3);
+    if (neng > 1 && !e->peer && (rc = sgm_create(&e->params, e->device, nullptr, &e->peer))) return rc;
+    if (neng > 2 && !e->peer2 && (rc = sgm_create(&e->params, e->device, nullptr, &e->peer2))) return rc;
+    sgm_engine *eng[3] = {e, e->peer, e->peer2};
+    for (int k = 0; k < neng; k++) {
         sgm_engine *q = eng[k];
         q->keep_aggr = 0;
         q->profile = 0;
@@ -1163,30 +1201,33 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
         q->debug = e->debug;
         q->prepass_rows = e->prepass_rows;
         if ((rc = q->in_left.ensure(npx)) || (rc = q->in_right.ensure(npx)) || (rc = q->disp_out.ensure(npx * 2))) return rc;
+        if ((rc = q->pin_left.ensure(npx)) || (rc = q->pin_right.ensure(npx)) || (rc = q->pin_disp.ensure(npx * 2))) return rc;
         if (xyz_out && ((rc = q->f32.ensure(npx * 4)) || (rc = q->xyz.ensure(npx * 12)))) return rc;
+        if (!q->ev_done) HIP_TRY(hipEventCreateWithFlags(&q->ev_done, hipEventDisableTiming));
     }
-    // results of pair i are fetched right before its engine is reused for pair i + 2 (pageable host
-    // memory: each copy blocks the host until the engine's stream reaches it -- the other engine
-    // keeps the GPU busy meanwhile)
-    auto fetch = [&](int i) -> int {
-        sgm_engine *q = eng[i & 1];
-        HIP_TRY(hipMemcpyAsync(disps_out + (size_t)i * npx, q->disp_out.p, npx * 2, hipMemcpyDeviceToHost, q->stream));
-        if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out + (size_t)i * npx * 3, q->xyz.p, npx * 12, hipMemcpyDeviceToHost, q->stream));
+    // results of pair i leave its engine right before the engine is reused for pair i + neng
+    auto finish = [&](int i) -> int {
+        sgm_engine *q = eng[i % neng];
+        HIP_TRY(hipEventSynchronize(q->ev_done));
+        std::memcpy(disps_out + (size_t)i * npx, q->pin_disp.p, npx * 2);
+        if (xyz_out) HIP_TRY(hipMemcpy(xyz_out + (size_t)i * npx * 3, q->xyz.p, npx * 12, hipMemcpyDeviceToHost));
         return SGM_OK;
     };
     for (int i = 0; i < N; i++) {
-        sgm_engine *q = eng[i & 1];
-        if (i >= 2 && (rc = fetch(i - 2))) return rc;
-        HIP_TRY(hipMemcpyAsync(q->in_left.p, lefts + (size_t)i * npx, npx, hipMemcpyHostToDevice, q->stream));
-        HIP_TRY(hipMemcpyAsync(q->in_right.p, rights + (size_t)i * npx, npx, hipMemcpyHostToDevice, q->stream));
+        sgm_engine *q = eng[i % neng];
+        if (i >= neng && (rc = finish(i - neng))) return rc;
+        std::memcpy(q->pin_left.p, lefts + (size_t)i * npx, npx);
+        std::memcpy(q->pin_right.p, rights + (size_t)i * npx, npx);
+        HIP_TRY(hipMemcpyAsync(q->in_left.p, q->pin_left.p, npx, hipMemcpyHostToDevice, q->stream));
+        HIP_TRY(hipMemcpyAsync(q->in_right.p, q->pin_right.p, npx, hipMemcpyHostToDevice, q->stream));
         rc = sgm_pipeline_device(q, q->in_left.p, q->in_right.p, H, W, W, Q16, q->disp_out.p, xyz_out ? q->f32.p : nullptr,
                                  xyz_out ? q->xyz.p : nullptr);
         if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(q->pin_disp.p, q->disp_out.p, npx * 2, hipMemcpyDeviceToHost, q->stream));
+        HIP_TRY(hipEventRecord(q->ev_done, q->stream));
     }
-    for (int i = std::max(0, N - 2); i < N; i++)
-        if ((rc = fetch(i))) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (N > 1) HIP_TRY(hipStreamSynchronize(e->peer->stream));
+    for (int i = std::max(0, N - neng); i < N; i++)
+        if ((rc = finish(i))) return rc;
     return SGM_OK;
 }
 

@@ -29,14 +29,14 @@ for mode in (0, 1):
     print(f"mode {mode}: host->host compute() {dt * 1e3:.1f} ms/pair = {H * W * D / dt / 1e6:.0f} Mdisp/s; "
           f"disp_to_float {1e3 * (t2 - t1):.1f} ms; reprojectImageTo3D (99.5 MB back) {1e3 * (t3 - t2):.1f} ms")
 
-# batch entry (sgm_compute_batch): N pairs in host memory, two in flight inside the engine
+# batch entry (sgm_compute_batch): N pairs in host memory, three in flight inside the engine
 import numpy as np  # noqa: E402
-N = 8
+N = 12
 L = np.stack([l] * N)
 R = np.stack([r] * N)
 for mode in (0, 1):
     eng = cv.get_engine(bench.sgbm_params(D, 7, mode))
-    eng.compute_batch_host(L[:2], R[:2], None)
+    eng.compute_batch_host(L[:3], R[:3], None)   # creates the peers and their buffers
     t0 = time.perf_counter()
     disps = eng.compute_batch_host(L, R, None)
     dt = (time.perf_counter() - t0) / N
