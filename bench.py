@@ -391,7 +391,7 @@ def main():
     # algorithmic model (unfused: 3 V per path scan) is kept as separate fields.
     _, W1 = eng.geometry(W)
     V = 2 * H * max(W1, 0) * D
-    R = min(9, max(4, -(-H // 240)))   # rows per sweep band (sweep_rows_for in sgm_engine.hip)
+    R = min(11, max(4, -(-H // (200 if mode else 240))))   # rows per sweep band (sweep_rows_for in sgm_engine.hip)
     launches = np.array([[n for _, _, n in st] for st in stage_acc]).mean(axis=0)
     by_kernel = {}
     for n, m, nl in zip(names, mean_ms, launches):
@@ -424,6 +424,13 @@ def main():
     else:
         basis = "pmc"
     achieved = (moved / (k_ms * 1e-3) / 1e9) if moved else None
+    # the same kernel where it has the GPU to itself (the downward pre-pass; the upward one shares it with the sweep)
+    alone = None
+    if "prepass_dn" in dom_stages and moved:
+        i = names.index("prepass_dn")
+        a_ms = float(mean_ms[i]) / max(1, int(launches[i]))
+        alone = {"stage": "prepass_dn", "avg_launch_ms": a_ms, "achieved": moved / (a_ms * 1e-3) / 1e9,
+                 "frac": moved / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     whole_traffic = sum(s.get("traffic_bytes_per_launch", 0) for s in pmc_stages.values()) or None
 
     frames = args.steps * ppg * world
@@ -468,6 +475,7 @@ def main():
                      "launches_per_step": by_kernel[kdom]["launches"] * ppg, "kernel_ms_per_frame": by_kernel[kdom]["ms"],
                      "algorithmic_bytes_per_launch": alg_launch,
                      "algorithmic_GBps": alg_launch / (k_ms * 1e-3) / 1e9,
+                     "alone": alone,
                      "note": "dominant = kernel with the largest total HIP-event time per frame (all stages); achieved = "
                              "bytes one launch moves (PMC 2*FETCH_SIZE+WRITE_SIZE of these kernels when basis=pmc, else "
                              "the design's minimal-traffic model) / average launch duration; the upward pre-pass shares "

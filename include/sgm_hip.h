@@ -127,6 +127,8 @@ int sgm_geometry(const sgm_params *params, int W, int *minX1, int *W1);
 /* ---- host-pointer entry points (blocking) ---- */
 int sgm_compute(sgm_engine *e, const uint8_t *left, const uint8_t *right, int H, int W,
                 int64_t stride_bytes, int16_t *disp_out /* H*W */);
+/* N dense pairs (tight rows); up to three pairs in flight on internal peer engines, images and disparity maps
+ * staged through page-locked buffers inside the engine (pageable caller memory is fine) */
 int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t *rights, int H,
                       int W, int16_t *disps_out /* N*H*W */, float *xyz_out /* N*H*W*3 or NULL */,
                       const double *Q16 /* needed iff xyz_out */);
