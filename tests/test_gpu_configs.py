@@ -173,6 +173,21 @@ def test_4k_small_d_schedule(D, mode):
     assert int((got != want).sum()) == 0, f"{int((got != want).sum())} of {got.size} differ"
 
 
+def test_4k_d512_hh_volumes_beyond_4_gib():
+    """The largest supported numDisparities at 4K, MODE_HH: W1 = 3328 columns, C and S of 7.4 GB each
+    (3.7 G elements: past 2^31 elements and past the 4 GiB a buffer descriptor spans).  This frame takes
+    the routes small frames only reach through debug switches -- the int16 cost pipeline (the byte
+    volume would pass 2 GiB), the pre-pass as three launches of the single-direction kernel with one
+    descriptor per row, NP = 4 sweeps -- with real 64-bit offsets."""
+    H, W, D, bs = 2160, 3840, 512, 7
+    l, r = pair(H, W, D, 1234)
+    p = nb_params(D, bs, 1)
+    want, _, _ = oracle_frame(l, r, p)
+    got, _, _, names = run_pipeline_device(l, r, p, None)
+    assert int((got != want).sum()) == 0, f"{int((got != want).sum())} of {got.size} differ"
+    assert {"cost_hsum", "cost_vsum", "sweep_dn", "sweep_up"} <= set(names)
+
+
 def test_notebook_setting_4k_d16_bs11():
     """The notebook as run (main.ipynb:781: ndisp=16, mindis=0, blockSize=11) on a 4K synthetic
     pair through the notebook-shaped functions.  bs=11 / P2=11616 is outside the worst-case
