@@ -138,9 +138,21 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
 // bytes) and removes what bounds k_sweep there: its instruction stream per pixel does not shrink
 // with D and three waves share the busiest SIMD.  Only the in-row path needs its minimum (the other
 // three are not propagated from here); S = sat(sum) as everywhere.  MODE: PATH_FIRST / PATH_ACCUM.
+// Per-row state of the small-D schedule (band height 1): one record of 3 * W1 * D int16 per row.  The grouped
+// pre-pass writes it ROLE-MAJOR, [row][role][x][D]: a wave (one role, 64 / GW adjacent columns) then stores
+// 64 / GW * D * 2 contiguous bytes -- whole lines; in the band layout [row][x][role][D] of the large-D
+// kernels each pixel's piece is D * 2 bytes (32 at D = 16) at a stride of three: partial-line writes that
+// every line of the record sees three times.  role_major = 0: the band layout, for records written by the
+// single-direction kernel (debug 16).
+__device__ __forceinline__ int bnd_px_off(int role_major, int W1, int x, int role)
+{
+    return role_major ? role * W1 + x : x * 3 + role;
+}
+
 template <int GW, int MODE>
 __global__ __launch_bounds__(64) void k_rows4_g(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
-                                                int16_t *__restrict__ S, const int16_t *__restrict__ bnd)
+                                                int16_t *__restrict__ S, const int16_t *__restrict__ bnd,
+                                                int role_major /* layout of bnd: see bnd_px_off */)
 {
     constexpr int G = 64 / GW, NP = 1, PB = 8;
     constexpr int OOB = (int)0xfffffff0u;  // beyond every descriptor used here (they span < 4 GiB)
@@ -184,9 +196,9 @@ __global__ __launch_bounds__(64) void k_rows4_g(Geom g, int xdir, int ydir, cons
                 const int xa = min(max(x - xdir, 0), W1 - 1), xc = min(max(x + xdir, 0), W1 - 1);
                 buf_load<NP>(pb[u].c, Cv, voff, x * pxb);
                 if (READS_S) buf_load<NP>(pb[u].s, Sv, voff, x * pxb);
-                buf_load<NP>(pb[u].qa, Bv, bvoff, (xa * 3 + 0) * pxb);
-                buf_load<NP>(pb[u].qb, Bv, bvoff, (x * 3 + 1) * pxb);
-                buf_load<NP>(pb[u].qc, Bv, bvoff, (xc * 3 + 2) * pxb);
+                buf_load<NP>(pb[u].qa, Bv, bvoff, bnd_px_off(role_major, W1, xa, 0) * pxb);
+                buf_load<NP>(pb[u].qb, Bv, bvoff, bnd_px_off(role_major, W1, x, 1) * pxb);
+                buf_load<NP>(pb[u].qc, Bv, bvoff, bnd_px_off(role_major, W1, xc, 2) * pxb);
             }
     };
     auto pixel = [&](const Px &p, int k) {
@@ -315,10 +327,10 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
             path_normalise<NP, true>(N[1], mm[0] >> 16, active, L[1]);
             path_normalise<NP, true>(N[2], m2, active, L[2]);
         }
-        // the state the row s + 1 will read: bnd[s + 1][column][role][D]
+        // the state the row s + 1 will read: bnd[s + 1][role][column][D] (role-major: bnd_px_off)
 #pragma unroll
         for (int d = 0; d < NR; d++) {
-            const int off = (active && s + 1 < H) ? (int)(((uint32_t)(s + 1) * (uint32_t)W1 + (uint32_t)xc[d]) * 3u + (uint32_t)(role0 + d)) * pxb + li * 4 : OOB;
+            const int off = (active && s + 1 < H) ? (int)(((uint32_t)(s + 1) * 3u + (uint32_t)(role0 + d)) * (uint32_t)W1 + (uint32_t)xc[d]) * pxb + li * 4 : OOB;
             buf_store<NP>(L[d], Bv, off, 0);
             xc[d] += rx[d];
             if (wrapped(xc[d])) L[d].fill(init);  // (per lane: a select)
@@ -344,7 +356,8 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
 // Same arithmetic as k_rows4_g without its in-row path.  MODE: PATH_FIRST / PATH_ACCUM.
 template <int GW, int MODE>
 __global__ __launch_bounds__(256) void k_vert3_g(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
-                                                 int16_t *__restrict__ S, const int16_t *__restrict__ bnd)
+                                                 int16_t *__restrict__ S, const int16_t *__restrict__ bnd,
+                                                 int role_major /* layout of bnd: see bnd_px_off */)
 {
     constexpr int G = 64 / GW, NP = 1;
     constexpr int OOB = (int)0xfffffff0u;
@@ -377,9 +390,9 @@ __global__ __launch_bounds__(256) void k_vert3_g(Geom g, int xdir, int ydir, con
         Pack<NP> c, sp, QA, QB, QC;
         buf_load<NP>(c, Cv, voff, 0);
         if (MODE == PATH_ACCUM) buf_load<NP>(sp, Sv, voff, 0);
-        buf_load<NP>(QA, Bv, rd ? (int)(brow + (uint32_t)(xa * 3 + 0) * pxb) + li * 4 : OOB, 0);
-        buf_load<NP>(QB, Bv, rd ? (int)(brow + (uint32_t)(x * 3 + 1) * pxb) + li * 4 : OOB, 0);
-        buf_load<NP>(QC, Bv, rd ? (int)(brow + (uint32_t)(xc * 3 + 2) * pxb) + li * 4 : OOB, 0);
+        buf_load<NP>(QA, Bv, rd ? (int)(brow + (uint32_t)bnd_px_off(role_major, W1, xa, 0) * pxb) + li * 4 : OOB, 0);
+        buf_load<NP>(QB, Bv, rd ? (int)(brow + (uint32_t)bnd_px_off(role_major, W1, x, 1) * pxb) + li * 4 : OOB, 0);
+        buf_load<NP>(QC, Bv, rd ? (int)(brow + (uint32_t)bnd_px_off(role_major, W1, xc, 2) * pxb) + li * 4 : OOB, 0);
         // out-of-image predecessors and idle lanes: start state / sentinel
         if (k == 0) QA.fill(0u);
         if (k == W1 - 1) QC.fill(0u);

@@ -730,6 +730,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 const bool last = pass == npass - 1 && g.mode == 1 && fused_wta && !rows4;
                 SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug, 0};
                 if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up")))) return rc;
+                // per-row state written by the grouped pre-pass: role-major; by the single-direction kernel (debug 16): band layout
+                const int rmaj = (e->debug & 16) ? 0 : 1;
                 if (rows4 && !(e->debug & 4096)) {
                     // D <= 64, band height 1: the three directions from the previous row are element-wise given the
                     // pre-pass state of every row (k_vert3_g, one streaming pass over all pixels); only the in-row
@@ -738,8 +740,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     const int16_t *bq = (const int16_t *)bl;
 #define SGM_VERT(GW_)                                                                                            \
     do {                                                                                                         \
-        if (pass == 0) hipLaunchKernelGGL((k_vert3_g<GW_, PATH_FIRST>), grid, block, 0, st, g, xdir, ydir, C, S, bq); \
-        else hipLaunchKernelGGL((k_vert3_g<GW_, PATH_ACCUM>), grid, block, 0, st, g, xdir, ydir, C, S, bq);      \
+        if (pass == 0) hipLaunchKernelGGL((k_vert3_g<GW_, PATH_FIRST>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
+        else hipLaunchKernelGGL((k_vert3_g<GW_, PATH_ACCUM>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
     } while (0)
                     if (GWs == 8) SGM_VERT(8);
                     else if (GWs == 16) SGM_VERT(16);
@@ -751,8 +753,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     const int16_t *bq = (const int16_t *)bl;
 #define SGM_ROWS4(GW_)                                                                                          \
     do {                                                                                                        \
-        if (pass == 0) hipLaunchKernelGGL((k_rows4_g<GW_, PATH_FIRST>), grid, block, 0, st, g, xdir, ydir, C, S, bq); \
-        else hipLaunchKernelGGL((k_rows4_g<GW_, PATH_ACCUM>), grid, block, 0, st, g, xdir, ydir, C, S, bq);     \
+        if (pass == 0) hipLaunchKernelGGL((k_rows4_g<GW_, PATH_FIRST>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
+        else hipLaunchKernelGGL((k_rows4_g<GW_, PATH_ACCUM>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
     } while (0)
                     if (GWs == 8) SGM_ROWS4(8);
                     else if (GWs == 16) SGM_ROWS4(16);
