@@ -129,8 +129,8 @@ def test_c5_4k_d256_5path_pipeline_device_with_xyz():
 
 
 def test_c4_batch_1080p_d128_both_batch_entries():
-    """configs[3], one GPU's share reduced to 5 frames (odd: the two engines of the two-in-flight
-    batch path end differently): sgm_compute_batch (host pointers, XYZ) and dist.hip_batch_compute
+    """configs[3], one GPU's share reduced to 5 frames (not a multiple of the three engines the batch
+    path keeps in flight: they end differently): sgm_compute_batch (host pointers, page-locked staging, XYZ) and dist.hip_batch_compute
     (device tensors, XYZ) -- the entry the sharded multi-GPU path calls on every rank."""
     import torch
     import stereo_reconstruction_cv_amd as cv
