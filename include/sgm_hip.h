@@ -101,7 +101,9 @@ typedef enum {
                               * the four-direction row kernel (round 1) instead of per-role pre-pass + element-wise
                               * vertical kernel + in-row kernel;  8192: that small-D schedule for D <= 32 only;
                               * 16384: D = 256, the upward pre-pass (the one beside the sweep) with prefetch
-                              * blocks of 2 rows (70 registers instead of 106) */
+                              * blocks of 2 rows (70 registers instead of 106);  65536: MODE_SGBM with D <= 128: the fifth
+                              * path after the sweep, accumulating into S, instead of beside it into a volume of its
+                              * own that the winner-take-all adds */
 } sgm_option;
 
 #define SGM_MAX_STAGES 32

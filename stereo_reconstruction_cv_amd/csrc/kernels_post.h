@@ -79,11 +79,30 @@ __global__ __launch_bounds__(256) void k_select(Geom g, const uint2 *__restrict_
 // selection loop of oracle/sgbm_oracle.c.
 constexpr int wta_t_stride(int D) { return D * 2 + 8; }  // bytes per staged pixel row (8-byte aligned, breaks the bank stride)
 
+// S = sat(S + S2), element-wise: only when the aggregated volume is kept for inspection (SGM_OPT_KEEP_AGGR)
+// after a frame whose fifth path went into a volume of its own.
+__global__ __launch_bounds__(256) void k_add_sat(int16_t *__restrict__ S, const int16_t *__restrict__ S2, int64_t n8)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    uint4 a = reinterpret_cast<uint4 *>(S)[i];
+    const uint4 b = reinterpret_cast<const uint4 *>(S2)[i];
+    a.x = pk_adds_s(a.x, b.x);
+    a.y = pk_adds_s(a.y, b.y);
+    a.z = pk_adds_s(a.z, b.z);
+    a.w = pk_adds_s(a.w, b.w);
+    reinterpret_cast<uint4 *>(S)[i] = a;
+}
+
 // LG = log2(chunks per row) when D is a power of two (16..512): compile-time trip counts, the next
 // block's loads prefetched into registers during the current block's scan.  LG = -1: any D
 // (multiple of 16), plain staging.
-template <bool POSW, int LG>
-__global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict__ S, uint2 *__restrict__ wta, int64_t npix)
+// TWO: the costs are the saturating sum of two volumes, S + S2 (MODE_SGBM with D <= 128: the fifth path runs
+// beside the sweep into a volume of its own; every path cost is >= 0 and the sum saturates, so the order of
+// the additions does not matter -- kernels_path.h).
+template <bool POSW, int LG, bool TWO = false>
+__global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict__ S, uint2 *__restrict__ wta, int64_t npix,
+                                              const int16_t *__restrict__ S2 = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t rows[];
     const int lane = threadIdx.x, D = LG >= 0 ? (8 << LG) : g.D, W1 = g.W1;
@@ -91,7 +110,7 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
     const int cpr = D * 2 / 16;  // 16-byte chunks per pixel row; a lane moves cpr chunks per block
     const int64_t nblocks = (npix + 63) / 64;
     constexpr int PF = LG < 0 ? 8 : (LG >= 5 ? 32 : (1 << LG));  // chunks per lane held in registers
-    uint4 v[PF];
+    uint4 v[PF], v2[TWO ? PF : 1];
     // chunk c = lane + 64 k of the block's contiguous 64 * D * 2 bytes: loads with a clamped index
     // (no branch between them), committed to the padded LDS rows afterwards
     auto issue = [&](int64_t blk, int k0) {
@@ -100,6 +119,21 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
         const uint4 *src = reinterpret_cast<const uint4 *>(S + blk * 64 * D);
 #pragma unroll
         for (int u = 0; u < PF; u++) v[u] = src[min(lane + 64 * (k0 + u), total - 1)];
+        if constexpr (TWO) {
+            const uint4 *src2 = reinterpret_cast<const uint4 *>(S2 + blk * 64 * D);
+#pragma unroll
+            for (int u = 0; u < PF; u++) v2[u] = src2[min(lane + 64 * (k0 + u), total - 1)];
+        }
+    };
+    auto summed = [&](int u) {  // chunk u of the cost rows: S, or sat(S + S2)
+        uint4 r = v[u];
+        if constexpr (TWO) {
+            r.x = pk_adds_s(r.x, v2[u].x);
+            r.y = pk_adds_s(r.y, v2[u].y);
+            r.z = pk_adds_s(r.z, v2[u].z);
+            r.w = pk_adds_s(r.w, v2[u].w);
+        }
+        return r;
     };
     auto commit = [&](int64_t blk, int k0) {
         const int64_t left = npix - blk * 64;
@@ -110,8 +144,9 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
             if (c < total) {
                 const int px = LG >= 0 ? c >> LG : c / cpr, w = c - px * cpr;
                 uint2 *dst = reinterpret_cast<uint2 *>(rows + px * stride + w * 16);
-                dst[0] = make_uint2(v[u].x, v[u].y);
-                dst[1] = make_uint2(v[u].z, v[u].w);
+                const uint4 q = summed(u);
+                dst[0] = make_uint2(q.x, q.y);
+                dst[1] = make_uint2(q.z, q.w);
             }
         }
     };
@@ -137,8 +172,9 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
                 if (k0 + u < cpr && c < total) {
                     const int px = c / cpr, w = c - px * cpr;
                     uint2 *dst = reinterpret_cast<uint2 *>(rows + px * stride + w * 16);
-                    dst[0] = make_uint2(v[u].x, v[u].y);
-                    dst[1] = make_uint2(v[u].z, v[u].w);
+                    const uint4 q = summed(u);
+                    dst[0] = make_uint2(q.x, q.y);
+                    dst[1] = make_uint2(q.z, q.w);
                 }
             }
         }

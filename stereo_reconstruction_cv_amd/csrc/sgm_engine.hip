@@ -124,6 +124,7 @@ struct sgm_engine {
     DevBuf in_left, in_right;           // staging for host-pointer calls
     DevBuf lrec, rplanes;               // features
     DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
+    DevBuf aggr2;                       // MODE_SGBM, D <= 128: the fifth path's own volume (added to S by the winner-take-all)
     DevBuf wta;                         // uint2 [H][W]
     DevBuf bndL, bndL2;                 // band-boundary state of the sweep pre-pass (down / up)
     DevBuf pstate, pstate2;             // line state between the row chunks of the pre-pass (ping-pong, down / up)
@@ -713,6 +714,29 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // 0.44 + 0.10).  debug 2 forces the fused form everywhere, debug 2048 the separate one (A/B, cross-check).
             const bool fused_wta = !(e->debug & 2048) && (((e->debug & 2) != 0 && !rows4) ||
                                                           (g.mode == 0 && ((e->debug & 4) || g.D > 128)));
+            // MODE_SGBM with the separate winner-take-all (D <= 128): the fifth path (in-row, right to left) needs
+            // nothing but C, so it runs on the auxiliary stream from here on, as a FIRST pass into a volume of its
+            // own (2 V of traffic instead of the 3 V of "S +="), beside the pre-pass and the sweep -- which at these
+            // D are bound by instruction issue, not by HBM; k_wta_t adds the two volumes while it stages them.
+            // debug 65536: the fifth path after the sweep, accumulating into S (A/B).
+            const bool two_vol = g.mode == 0 && !fused_wta && g.D <= 128 && !(e->debug & 4) && !(e->debug & 65536);
+            int16_t *S2 = nullptr;
+            if (two_vol) {
+                if ((rc = e->aggr2.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
+                S2 = (int16_t *)e->aggr2.p;
+                if (!e->aux) {
+                    HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(e->ev_fork, st));
+                HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+                if ((rc = stage_begin(e, "path_W", e->aux))) return rc;
+                launch_rows_grouped(g, H, group_width(g, H), -1, PATH_FIRST, C, S2, 1, wta, e->aux);
+                KCHECK();
+                if ((rc = stage_end(e, 1, e->aux))) return rc;
+                HIP_TRY(hipEventRecord(e->ev_join, e->aux));
+            }
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
@@ -766,7 +790,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 KCHECK();
                 if ((rc = stage_end(e, 1))) return rc;
             }
-            if (g.mode == 0) {
+            if (two_vol) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+            if (g.mode == 0 && !two_vol) {
                 if ((rc = stage_begin(e, fused_wta ? "path_W_wta" : "path_W"))) return rc;
                 const int GW = (e->debug & 4) ? 64 : group_width(g, H);  // debug 4: no lane groups (A/B)
                 const int pm = fused_wta ? PATH_LAST : PATH_ACCUM;
@@ -789,7 +814,26 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         if (lds > 48 * 1024)                                                                                           \
             HIP_TRY(hipFuncSetAttribute((const void *)k_wta_t<POSW_, LG_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                                    \
-        hipLaunchKernelGGL((k_wta_t<POSW_, LG_>), grid, block, lds, st, g, (const int16_t *)S, wta, npix);               \
+        hipLaunchKernelGGL((k_wta_t<POSW_, LG_>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,              \
+                           (const int16_t *)nullptr);                                                                  \
+    } while (0)
+#define SGM_WTA2(POSW_, LG_)                                                                                           \
+    do {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                           \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_wta_t<POSW_, LG_, true>,                                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hipLaunchKernelGGL((k_wta_t<POSW_, LG_, true>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,        \
+                           (const int16_t *)S2);                                                                       \
+    } while (0)
+#define SGM_WTA2_LG(POSW_)                      \
+    do {                                        \
+        switch (lgc) {                          \
+        case 1: SGM_WTA2(POSW_, 1); break;      \
+        case 2: SGM_WTA2(POSW_, 2); break;      \
+        case 3: SGM_WTA2(POSW_, 3); break;      \
+        case 4: SGM_WTA2(POSW_, 4); break;      \
+        default: SGM_WTA2(POSW_, -1); break;    \
+        }                                       \
     } while (0)
 #define SGM_WTA_LG(POSW_)                       \
     do {                                        \
@@ -803,8 +847,17 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         default: SGM_WTA(POSW_, -1); break;     \
         }                                       \
     } while (0)
-                if (g.uniq < 100) SGM_WTA_LG(true);
+                if (two_vol) {
+                    if (g.uniq < 100) SGM_WTA2_LG(true);
+                    else SGM_WTA2_LG(false);
+                    if (e->keep_aggr) {  // the volume a caller inspects is the whole sum
+                        const int64_t n8 = (int64_t)g.rowsz * H / 8;  // rowsz = W1 * D is a multiple of 16
+                        hipLaunchKernelGGL(k_add_sat, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, S, (const int16_t *)S2, n8);
+                    }
+                } else if (g.uniq < 100) SGM_WTA_LG(true);
                 else SGM_WTA_LG(false);
+#undef SGM_WTA2_LG
+#undef SGM_WTA2
 #undef SGM_WTA_LG
 #undef SGM_WTA
                 KCHECK();
@@ -935,7 +988,7 @@ void sgm_destroy(sgm_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2, &e->pstate, &e->pstate2,
+    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->aggr2, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2, &e->pstate, &e->pstate2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
                       &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom};
     for (DevBuf *b : bufs) b->release();

@@ -32,14 +32,15 @@ def test_large_blocks_and_high_prefilter_caps(H, W, D, bs, cap, mode):
         assert not bad, f"schedule {schedule}: " + "\n".join(bad)
 
 
-@pytest.mark.parametrize("debug", [8, 16, 32, 128, 16 | 32, 4, 4 | 16, 512, 4096, 8192, 4096 | 8192])
+@pytest.mark.parametrize("debug", [8, 16, 32, 128, 16 | 32, 4, 4 | 16, 512, 4096, 8192, 4096 | 8192, 65536, 65536 | 4096])
 @pytest.mark.parametrize("H,W,D,bs,mode", [(45, 420, 256, 7, 1), (38, 300, 64, 5, 1), (41, 200, 16, 11, 0), (29, 640, 160, 5, 0)])
 def test_debug_switches_keep_results(debug, H, W, D, bs, mode):
     """8: k_vsum_ring with 4 int16 per thread; 16: the pre-pass as three launches of the single-direction
     kernel (what frames with rowsz*H >= 2^31 take); 32: no auxiliary stream; 128: fork before the
     downward pre-pass; 4: no lane groups; 4096: small D with the round-1 kernels (three-role grouped
     pre-pass, k_rows4_g) instead of per-role pre-pass + k_vert3_g + k_rows_g; 8192: that schedule for
-    D <= 32 only.  Results must not change; 256 (int16 cost pipeline) is in
+    D <= 32 only; 65536: MODE_SGBM's fifth path after the sweep (S +=) instead of beside it into its own
+    volume.  Results must not change; 256 (int16 cost pipeline) is in
     test_gpu_parity.py::test_both_winner_take_all_forms."""
     l, r, _ = synth.make_pair(H, W, D, 300 + debug)
     p = U.params(D, bs, 0, mode, speckleWindowSize=30, speckleRange=2)
