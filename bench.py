@@ -55,12 +55,16 @@ WORKLOADS = {
              "3840x2160 D=256 bs=7 MODE_HH 8-path + LR + subpixel + median + speckle + reprojectImageTo3D"),
     "c3c5x2": (2160, 3840, 256, 7, 1, 2, True,
                "two concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on two HIP streams (+ reproject)"),
+    "c3c5x3": (2160, 3840, 256, 7, 1, 3, True, "three concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on three HIP streams (+ reproject)"),
+    "c3c5x4": (2160, 3840, 256, 7, 1, 4, True, "four concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on four HIP streams (+ reproject)"),
+    "c3c5x6": (2160, 3840, 256, 7, 1, 6, True, "six concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on six HIP streams (+ reproject)"),
     "nb": (2160, 3840, 16, 11, 0, 1, True, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
     "tiny": (96, 480, 64, 7, 1, 2, True, "96x480 D=64 MODE_HH x2 (launcher rehearsal only, not a BASELINE config)"),
 }
 
 # stage (HIP-event bracket inside the engine) -> kernel that runs in it, for the roofline record
 STAGE_KERNEL = {
+    "chain_dn": "k_sweep_chain<NP,*,SWEEP_FIRST>", "chain_up": "k_sweep_chain<NP,*,SWEEP_ACCUM>",
     "sweep_dn": "k_sweep<NP,*,SWEEP_FIRST>", "sweep_up": "k_sweep<NP,*,SWEEP_ACCUM>", "sweep_up_wta": "k_sweep<NP,*,SWEEP_LAST>",
     "prepass_dn": "k_prepass3<NP,*>", "prepass_up": "k_prepass3<NP,*>", "path_W_wta": "k_rows_g<64,NP,*,PATH_LAST>",
     "path_W": "k_rows_g<GW,NP,*,PATH_ACCUM>", "wta": "k_wta_t", "cost_pix": "k_pix<NP>", "cost_box": "k_box_u8<R,NP>",
@@ -189,7 +193,8 @@ def main():
     ap.add_argument("--stages", action="store_true", help="print the per-stage HIP-event table to stderr")
     ap.add_argument("--concurrent", type=int, default=0,
                     help="engines (HIP streams) working on different pairs at the same time; 0 = workload default")
-    ap.add_argument("--schedule", type=int, default=1, help="0: one kernel per path direction, 1: fused sweeps")
+    ap.add_argument("--schedule", type=int, default=1, help="0: one kernel per path direction, 1: fused sweeps behind a pre-pass, 2: chained sweeps (no pre-pass)")
+    ap.add_argument("--chain-wgs", type=int, default=0, help="schedule 2: workgroups per sweep launch (0 = automatic)")
     ap.add_argument("--debug", type=int, default=0, help="SGM_OPT_DEBUG bit mask (A/B measurements; include/sgm_hip.h)")
     ap.add_argument("--prepass-rows", type=int, default=0, help="rows per chunk of the boundary pre-pass (0 = automatic)")
     ap.add_argument("--sweep-rows", type=int, default=0, help="rows per band of the fused sweeps (0 = automatic)")
@@ -279,6 +284,8 @@ def main():
             e.set_option(_lib.SGM_OPT_PREPASS_ROWS, args.prepass_rows)
         if not mock and args.sweep_rows:
             e.set_option(_lib.SGM_OPT_SWEEP_ROWS, args.sweep_rows)
+        if not mock and args.chain_wgs:
+            e.set_option(_lib.SGM_OPT_CHAIN_WGS, args.chain_wgs)
         engines.append(e)
     eng = engines[0]
 
@@ -455,7 +462,7 @@ def main():
         "config": {"workload": f"{args.workload}: {desc}", "height": H, "width": W, "numDisparities": D,
                    "blockSize": bs, "mode": "MODE_HH" if mode else "MODE_SGBM", "pairs_per_gpu_per_step": ppg,
                    "global_pairs_per_step": ppg * world, "streams_per_gpu": nconc,
-                   "schedule": "fused sweeps" if args.schedule else "one kernel per direction",
+                   "schedule": ("one kernel per direction", "fused sweeps", "chained sweeps")[args.schedule],
                    **({"debug_mask": args.debug} if args.debug else {}),
                    "world_size": dist.get_world_size() if world > 1 else 1,
                    "frames_per_rank": [b - a for a, b in (sharding.shard_range(ppg * world, r, world) for r in range(world))],

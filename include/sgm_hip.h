@@ -85,8 +85,11 @@ typedef enum {
 typedef enum {
     SGM_OPT_KEEP_AGGR = 0,   /* 1: the last path kernel also stores S (debug; costs bandwidth)   */
     SGM_OPT_PROFILE = 1,     /* 1: bracket every stage with HIP events on the engine's stream    */
-    SGM_OPT_SCHEDULE = 2,    /* 0: one kernel per path direction; 1 (default): fused 4-direction sweeps */
+    SGM_OPT_SCHEDULE = 2,    /* 0: one kernel per path direction; 1 (default): fused 4-direction sweeps behind a boundary
+                              * pre-pass (lowest latency of one pair); 2: chained sweeps, no pre-pass (throughput mode: fewer
+                              * bytes per pair, one pair alone is slower -- meant for several pairs in flight) */
     SGM_OPT_SWEEP_ROWS = 3,  /* rows per band of the fused sweep; 0 = automatic                  */
+    SGM_OPT_CHAIN_WGS = 6,   /* schedule 2: workgroups (bands in flight) per sweep launch; 0 = automatic       */
     SGM_OPT_PREPASS_ROWS = 5, /* rows per chunk (= launch) of the boundary pre-pass; 0 = automatic (about 135, a multiple of 8) */
     SGM_OPT_DEBUG = 4        /* A/B switches for measurements, a bit mask.  Results stay correct except
                               * for bit 64.   2: winner-take-all fused into the last path kernel

@@ -36,7 +36,10 @@ struct SweepArgs {
     uint2 *wta;
     int keepS;
     int dbg;  // timing experiments only (results become wrong): 64 = loader wave skips its HBM loads
-    int band0;  // the launch covers bands band0 .. band0 + gridDim.x - 1 (row-chunk pipelining of the first pass)
+    // chained schedule only (k_sweep_chain): bndL is then the record the bands hand to each other
+    uint32_t *ctl;  // [0] band ticket, [1 + b] = pixels of band b's last row that have reached HBM; zeroed before every launch
+    uint32_t *err;  // sticky, never reset by a launch: set when a bounded wait gave up
+    int nbands;
 };
 
 constexpr int SWEEP_MAX_ROWS = 11;  // compute waves per workgroup (768 threads = 3 waves per SIMD -> 168 VGPRs per lane)
@@ -79,174 +82,245 @@ __device__ __forceinline__ void lds_store(const Pack<NP> &p, uint32_t *dst)
 #ifndef SGM_NT_SWEEP_LOADS
 #define SGM_NT_SWEEP_LOADS 1
 #endif
-template <int NP, bool PARTIAL, int MODE, bool POSW>
-__global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, SweepArgs a)
+// ---- the waves of a band ---------------------------------------------------------------------------
+// The body of a band is the same in the plain schedule (k_sweep: one workgroup per band, the state of
+// the row above the band comes from the pre-pass) and in the chained one (k_sweep_chain: the state comes
+// from the band above, through HBM, as that band produces it).  Every wave of a workgroup passes
+// exactly 1 + T workgroup barriers per band, T = ceil(W1 / PPS) + 2 (R - 1): barrier 0 closes the
+// prologue, barrier 1 + t closes lockstep step t.
+
+template <int NP>
+__device__ __forceinline__ void sweep_write_start_state(uint32_t *ring, int slot, uint32_t init)
 {
-    constexpr int LDAUX = SGM_NT_SWEEP_LOADS ? 2 : 0;  // "nt": every byte the sweep loads is used once
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr int SLOT = sweep_slot_dwords(NP), ROLE = 64 * NP;
+    Pack<NP> v;
+    v.fill(init);
+#pragma unroll
+    for (int d = 0; d < 3; d++) lds_store<NP>(v, ring + slot * SLOT + d * ROLE);
+}
+
+// Chained schedule: progress word of the band above (number of pixels of its last row, in sweep order,
+// whose three path states are in HBM).  Polled by the loader wave only; relaxed agent-scope loads
+// ("sc1": served behind this CU's L1), the payload is then read with sc1 loads as well
+// (cdna_hip_programming.md Guideline 16, R1 with the measured sc1-load form: one lane of the producer
+// stores the flag after its wave's payload stores are complete, the polling wave loads after its poll
+// has matched).  Every wait is bounded: after about 0.25 s it gives up, raises *err and lets the band
+// run on (its results are then wrong and the host reports SGM_ERR_HIP) -- the grid always drains.
+struct ChainWait {
+    const uint32_t *word = nullptr;  // progress word of the band above (nullptr: nothing to wait for)
+    uint32_t *err = nullptr;
+    uint32_t seen = 0;
+    uint32_t pending = 0;  // a poll issued one prefetch block ago: by the time it is looked at, it has long returned
+    __device__ __forceinline__ uint32_t peek() const
+    {
+        return __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    // Block boundary of the loader: take the poll issued a block ago, wait (rarely) for `need` pixels, issue the
+    // next poll -- in front of the block's loads, so that it never returns later than data the wave waits for anyway.
+    __device__ __forceinline__ void step(uint32_t need)
+    {
+        if (!word) return;
+        seen = max(seen, (uint32_t)__builtin_amdgcn_readfirstlane(pending));
+        until(need);
+        pending = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void until(uint32_t need)
+    {
+        if (seen >= need) return;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        for (;;) {
+            seen = peek();
+            if (seen >= need) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) {
+                if (lane_id() == 0) atomicOr(err, 1u);
+                seen = 0x7fffffffu;  // this workgroup stops waiting for good
+                break;
+            }
+        }
+    }
+};
+
+// ==== loader wave: state of the row above the band, HBM -> registers -> LDS ring 0, ahead of wave 0 ====
+template <int NP, bool PARTIAL, bool CHAIN>
+__device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs &a, int band, int lane, uint32_t *lds)
+{
+    // plain schedule: every byte is used once -> "nt"; chained: the record was written by another CU a
+    // moment ago -> "sc1" (agent scope: not from this CU's L1)
+    constexpr int LDAUX = CHAIN ? 16 : (SGM_NT_SWEEP_LOADS ? 2 : 0);
     constexpr int PPS = sweep_pps(NP);
     constexpr int RING = sweep_ring(NP);
     constexpr int PB = RING;  // prefetch block (pixels) = ring depth, so slot(k) = k % PB is static
     constexpr int SLOT = sweep_slot_dwords(NP);
     constexpr int ROLE = 64 * NP;  // dwords per role inside a slot
     const int R = a.R;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const int band = a.band0 + blockIdx.x;
-    const int W1 = g.W1, D = g.D, H = g.H;
+    const int W1 = g.W1, D = g.D;
     const int T = (W1 + PPS - 1) / PPS + 2 * (R - 1);  // lockstep steps
+    const bool active = !PARTIAL || (2 * NP * lane < D);
+    const int lane_off = active ? 2 * NP * lane : 0;
+    const uint32_t init = active ? 0u : SGM_SENT;
+    uint32_t *const ring0 = lds + lane * NP;
+
+    const bool has_prev = band > 0 && !(a.dbg & 64);
+    Pack<NP> bA[PB][3], bB[PB][3];
+    // this band's boundary row as a buffer resource: [x][3 roles][D] int16
+    const int row_bytes = W1 * 3 * D * 2;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.bndL + (int64_t)band * W1 * 3 * D), 0, row_bytes, 0x00020000);
+    const int voff = lane_off * 2;
+    const int px_bytes = 3 * D * 2;
+    const int pk = a.xdir > 0 ? px_bytes : -px_bytes;           // byte step per pixel of the sweep order
+    const int p0 = a.xdir > 0 ? 0 : (W1 - 1) * px_bytes;
+    ChainWait cw;
+    if (CHAIN && has_prev) {
+        cw.word = a.ctl + band;  // = ctl[1 + (band - 1)]
+        cw.err = a.err;
+    }
+    // FULL = every pixel of the block exists: no guards, so hipcc can count the loads in flight
+    // (with a branch between issue and use it falls back to vmcnt(0) and the whole lockstep
+    // workgroup waits for HBM latency every block)
+    auto lb_t = [&](auto full_c, Pack<NP>(*b)[3], int k0) {
+        constexpr bool FULL = decltype(full_c)::value;
+        if (CHAIN) cw.step((uint32_t)min(k0 + PB, W1));  // (a block past the row's end waits for nothing new)
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            if (FULL || k0 + u < W1) {
+                const int so = p0 + (k0 + u) * pk;
+#pragma unroll
+                for (int d = 0; d < 3; d++) buf_load<NP, LDAUX>(b[u][d], rsrc, voff, so + d * D * 2);
+            }
+        }
+    };
+    auto wb_t = [&](auto full_c, Pack<NP>(*b)[3], int u, int k) {  // pixel k, k % PB == u
+        constexpr bool FULL = decltype(full_c)::value;
+        if (!FULL && k > W1) return;
+        uint32_t *slot = ring0 + u * SLOT;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            Pack<NP> v;
+            if (FULL || k < W1) {
+                v = b[u][d];
+                if (PARTIAL && !active) v.fill(SGM_SENT);
+            } else {
+                v.fill(init);  // the virtual pixel W1
+            }
+            lds_store<NP>(v, slot + d * ROLE);
+        }
+    };
+    int t = 0;  // lockstep steps done; step t writes pixels PPS*(t+2) .. PPS*(t+2)+PPS-1
+    if (!has_prev) {
+        // first band of the sweep: the row above is the all-zero start state everywhere
+#pragma unroll
+        for (int u = 0; u < RING; u++) sweep_write_start_state<NP>(ring0, u, init);
+        wg_barrier();
+        for (; t < T; t++) wg_barrier();
+        return;
+    }
+    sweep_write_start_state<NP>(ring0, RING - 1, init);
+    const std::true_type full{};
+    const std::false_type part{};
+    // prologue: pixels 0 .. 2*PPS-1, then the rest of block 0
+    if (2 * PB <= W1) {
+        lb_t(full, bA, 0);
+        lb_t(full, bB, PB);
+#pragma unroll
+        for (int p = 0; p < 2 * PPS; p++) wb_t(full, bA, p, p);
+        wg_barrier();
+#pragma unroll
+        for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) {
+#pragma unroll
+            for (int p = 0; p < PPS; p++) wb_t(full, bA, u0 + p, u0 + p);
+            wg_barrier();
+            t++;
+        }
+    } else {
+        lb_t(part, bA, 0);
+        lb_t(part, bB, PB);
+#pragma unroll
+        for (int p = 0; p < 2 * PPS; p++) wb_t(part, bA, p, p);
+        wg_barrier();
+#pragma unroll
+        for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) {
+            if (t < T) {
+#pragma unroll
+                for (int p = 0; p < PPS; p++) wb_t(part, bA, u0 + p, u0 + p);
+                wg_barrier();
+                t++;
+            }
+        }
+    }
+    int k0 = PB;  // bB holds block [k0, k0+PB), bA is free
+    // steady state: blocks k0 (in bB), k0+PB (to bA), k0+2PB (to bB) all full -> straight-line
+    for (; k0 + 3 * PB <= W1; k0 += 2 * PB) {
+        lb_t(full, bA, k0 + PB);
+#pragma unroll
+        for (int u0 = 0; u0 < PB; u0 += PPS) {
+#pragma unroll
+            for (int p = 0; p < PPS; p++) wb_t(full, bB, u0 + p, k0 + u0 + p);
+            wg_barrier();
+        }
+        lb_t(full, bB, k0 + 2 * PB);
+#pragma unroll
+        for (int u0 = 0; u0 < PB; u0 += PPS) {
+#pragma unroll
+            for (int p = 0; p < PPS; p++) wb_t(full, bA, u0 + p, k0 + PB + u0 + p);
+            wg_barrier();
+        }
+        t += 2 * (PB / PPS);
+    }
+    // tail: guarded blocks, then idle steps until every row has finished
+    for (; t < T; k0 += 2 * PB) {
+        lb_t(part, bA, k0 + PB);
+#pragma unroll
+        for (int u0 = 0; u0 < PB; u0 += PPS) {
+            if (t < T) {
+#pragma unroll
+                for (int p = 0; p < PPS; p++) wb_t(part, bB, u0 + p, k0 + u0 + p);
+                wg_barrier();
+                t++;
+            }
+        }
+        lb_t(part, bB, k0 + 2 * PB);
+#pragma unroll
+        for (int u0 = 0; u0 < PB; u0 += PPS) {
+            if (t < T) {
+#pragma unroll
+                for (int p = 0; p < PPS; p++) wb_t(part, bA, u0 + p, k0 + PB + u0 + p);
+                wg_barrier();
+                t++;
+            }
+        }
+    }
+}
+
+// ==== compute wave: one image row ======================================================================
+template <int NP, bool PARTIAL, int MODE, bool POSW>
+__device__ __forceinline__ void sweep_compute_wave(const Geom &g, const SweepArgs &a, int band, int wave, int lane, uint32_t *lds)
+{
+    constexpr int LDAUX = SGM_NT_SWEEP_LOADS ? 2 : 0;  // "nt": every byte the sweep loads is used once
+    constexpr int PPS = sweep_pps(NP);
+    constexpr int RING = sweep_ring(NP);
+    constexpr int PB = RING;
+    constexpr int SLOT = sweep_slot_dwords(NP);
+    constexpr int ROLE = 64 * NP;
+    const int R = a.R;
+    const int W1 = g.W1, D = g.D, H = g.H;
+    const int T = (W1 + PPS - 1) / PPS + 2 * (R - 1);
     const bool active = !PARTIAL || (2 * NP * lane < D);
     const int lane_off = active ? 2 * NP * lane : 0;
     const uint32_t init = active ? 0u : SGM_SENT;
     // ring 0 is fed by the loader (row above the band), ring r+1 by compute wave r
     uint32_t *const ring0 = lds + lane * NP;
 
-    // Out-of-image neighbours are ordinary ring slots holding the start state: "pixel -1" lives in
-    // slot RING-1 (written before the prologue barrier, not reused until pixel RING-1 exists) and
-    // "pixel W1" is written by each producer one step after its last real pixel.  The per-pixel
-    // code therefore needs no border branches.
-    auto write_start_state = [&](uint32_t *ring, int slot) {
-        Pack<NP> v;
-        v.fill(init);
-#pragma unroll
-        for (int d = 0; d < 3; d++) lds_store<NP>(v, ring + slot * SLOT + d * ROLE);
-    };
-
-    if (wave == R) {
-        // ==== loader wave: boundary state HBM -> registers -> LDS, 2 steps ahead of wave 0 ====
-        const bool has_prev = band > 0 && !(a.dbg & 64);
-        Pack<NP> bA[PB][3], bB[PB][3];
-        // this band's boundary row as a buffer resource: [x][3 roles][D] int16
-        const int row_bytes = W1 * 3 * D * 2;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(a.bndL + (int64_t)band * W1 * 3 * D), 0, row_bytes, 0x00020000);
-        const int voff = lane_off * 2;
-        const int px_bytes = 3 * D * 2;
-        const int pk = a.xdir > 0 ? px_bytes : -px_bytes;           // byte step per pixel of the sweep order
-        const int p0 = a.xdir > 0 ? 0 : (W1 - 1) * px_bytes;
-        // FULL = every pixel of the block exists: no guards, so hipcc can count the loads in flight
-        // (with a branch between issue and use it falls back to vmcnt(0) and the whole lockstep
-        // workgroup waits for HBM latency every block)
-        auto lb_t = [&](auto full_c, Pack<NP>(*b)[3], int k0) {
-            constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-                if (FULL || k0 + u < W1) {
-                    const int so = p0 + (k0 + u) * pk;
-#pragma unroll
-                    for (int d = 0; d < 3; d++) buf_load<NP, LDAUX>(b[u][d], rsrc, voff, so + d * D * 2);
-                }
-            }
-        };
-        auto wb_t = [&](auto full_c, Pack<NP>(*b)[3], int u, int k) {  // pixel k, k % PB == u
-            constexpr bool FULL = decltype(full_c)::value;
-            if (!FULL && k > W1) return;
-            uint32_t *slot = ring0 + u * SLOT;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                Pack<NP> v;
-                if (FULL || k < W1) {
-                    v = b[u][d];
-                    if (PARTIAL && !active) v.fill(SGM_SENT);
-                } else {
-                    v.fill(init);  // the virtual pixel W1
-                }
-                lds_store<NP>(v, slot + d * ROLE);
-            }
-        };
-        int t = 0;  // lockstep steps done; step t writes pixels PPS*(t+2) .. PPS*(t+2)+PPS-1
-        if (!has_prev) {
-            // first band of the sweep: the row above is the all-zero start state everywhere
-#pragma unroll
-            for (int u = 0; u < RING; u++) write_start_state(ring0, u);
-            wg_barrier();
-            for (; t < T; t++) wg_barrier();
-            return;
-        }
-        write_start_state(ring0, RING - 1);
-        const std::true_type full{};
-        const std::false_type part{};
-        // prologue: pixels 0 .. 2*PPS-1, then the rest of block 0
-        if (2 * PB <= W1) {
-            lb_t(full, bA, 0);
-            lb_t(full, bB, PB);
-#pragma unroll
-            for (int p = 0; p < 2 * PPS; p++) wb_t(full, bA, p, p);
-            wg_barrier();
-#pragma unroll
-            for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) {
-#pragma unroll
-                for (int p = 0; p < PPS; p++) wb_t(full, bA, u0 + p, u0 + p);
-                wg_barrier();
-                t++;
-            }
-        } else {
-            lb_t(part, bA, 0);
-            lb_t(part, bB, PB);
-#pragma unroll
-            for (int p = 0; p < 2 * PPS; p++) wb_t(part, bA, p, p);
-            wg_barrier();
-#pragma unroll
-            for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) {
-                if (t < T) {
-#pragma unroll
-                    for (int p = 0; p < PPS; p++) wb_t(part, bA, u0 + p, u0 + p);
-                    wg_barrier();
-                    t++;
-                }
-            }
-        }
-        int k0 = PB;  // bB holds block [k0, k0+PB), bA is free
-        // steady state: blocks k0 (in bB), k0+PB (to bA), k0+2PB (to bB) all full -> straight-line
-        for (; k0 + 3 * PB <= W1; k0 += 2 * PB) {
-            lb_t(full, bA, k0 + PB);
-#pragma unroll
-            for (int u0 = 0; u0 < PB; u0 += PPS) {
-#pragma unroll
-                for (int p = 0; p < PPS; p++) wb_t(full, bB, u0 + p, k0 + u0 + p);
-                wg_barrier();
-            }
-            lb_t(full, bB, k0 + 2 * PB);
-#pragma unroll
-            for (int u0 = 0; u0 < PB; u0 += PPS) {
-#pragma unroll
-                for (int p = 0; p < PPS; p++) wb_t(full, bA, u0 + p, k0 + PB + u0 + p);
-                wg_barrier();
-            }
-            t += 2 * (PB / PPS);
-        }
-        // tail: guarded blocks, then idle steps until every row has finished
-        for (; t < T; k0 += 2 * PB) {
-            lb_t(part, bA, k0 + PB);
-#pragma unroll
-            for (int u0 = 0; u0 < PB; u0 += PPS) {
-                if (t < T) {
-#pragma unroll
-                    for (int p = 0; p < PPS; p++) wb_t(part, bB, u0 + p, k0 + u0 + p);
-                    wg_barrier();
-                    t++;
-                }
-            }
-            lb_t(part, bB, k0 + 2 * PB);
-#pragma unroll
-            for (int u0 = 0; u0 < PB; u0 += PPS) {
-                if (t < T) {
-#pragma unroll
-                    for (int p = 0; p < PPS; p++) wb_t(part, bA, u0 + p, k0 + PB + u0 + p);
-                    wg_barrier();
-                    t++;
-                }
-            }
-        }
-        return;
-    }
-
-    // ==== compute wave: one image row ==============================================================
     const int j = band * R + wave;  // row index in sweep order
     const int y = a.ydir > 0 ? j : H - 1 - j;
     const uint32_t *const prev = ring0 + wave * RING * SLOT;
     uint32_t *const mine = ring0 + (wave + 1) * RING * SLOT;
-    write_start_state(mine, RING - 1);
+    // Out-of-image neighbours are ordinary ring slots holding the start state: "pixel -1" lives in
+    // slot RING-1 (written before the prologue barrier, not reused until pixel RING-1 exists) and
+    // "pixel W1" is written by each producer one step after its last real pixel.  The per-pixel
+    // code therefore needs no border branches.
+    sweep_write_start_state<NP>(mine, RING - 1, init);
     wg_barrier();  // prologue barrier
     if (j >= H) {  // row past the image (last band): keep the barrier count, do nothing
         for (int t = 0; t < T; t++) wg_barrier();
@@ -390,8 +464,135 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
     if (g.hr && lane == 0) headroom_raise(g.hr + 1, hm & 0xffffu);
     // one step after the last real pixel: the virtual pixel W1 (start state) for the row below
     if (wave < R - 1) {
-        write_start_state(mine, W1 % RING);
+        sweep_write_start_state<NP>(mine, W1 % RING, init);
         for (int i = 0; i < 2 * (R - 1 - wave); i++) wg_barrier();
+    }
+}
+
+template <int NP, bool PARTIAL, int MODE, bool POSW>
+__global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, SweepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int band = blockIdx.x;
+    if (wave == a.R) sweep_loader_wave<NP, PARTIAL, false>(g, a, band, lane, lds);
+    else sweep_compute_wave<NP, PARTIAL, MODE, POSW>(g, a, band, wave, lane, lds);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Chained schedule ("throughput mode", SGM_OPT_SCHEDULE = 2): no boundary pre-pass.  A band takes the
+// state of the row above it from the band above, which publishes the path state of its last row to HBM
+// while it computes; what a frame then moves per pass is "C read once, S written once" plus that record
+// (3 / R of a volume, written and read once) instead of the pre-pass's second and third read of C.
+//
+// Workgroup = R compute waves + loader wave (wave R) + publisher wave (wave R + 1).  The compute waves are
+// those of k_sweep, unchanged.  The publisher reads what compute wave R - 1 leaves in its LDS ring (in
+// k_sweep nobody reads that ring) one step later and stores it to the record of band + 1 with write-through
+// ("sc1") stores; it then advances the band's progress word to the pixels whose stores are known complete:
+// a counted s_waitcnt -- every lockstep step issues the same number of stores (those of pixels that do not
+// exist go to an offset past the record and are dropped by the bounds check), so "all but the stores of the
+// last KD steps" is a constant -- and never waits for an outstanding store.  The loader of band + 1 polls
+// that word (ChainWait) before it prefetches a block.
+//
+// Order and liveness.  Bands are not tied to blockIdx: a workgroup draws its band from a ticket counter
+// when it starts (and again after each band: the grid is persistent, a window of workgroups slides over
+// the bands), so the band above any band a workgroup waits for was drawn earlier -- by a workgroup that is
+// resident or has finished.  By induction down to band 0, which waits for nothing, every wait ends, for any
+// grid size, any dispatch order, and with other kernels sharing the GPU; a workgroup waits only for a lower
+// ticket of its own launch.  Barrier counts are those of k_sweep: 1 + T per band for every wave.
+//
+// What it costs.  A band trails the band above by LAG = 2 (R - 1) + about 15 steps, so a single frame's
+// pass is a chain of nbands * LAG + T steps (4K, D = 256, R = 11: about 8600 steps against T = 1812 for the
+// plain sweep) on T / LAG = about 50 workgroups: slower for one frame, but a frame needs only that many
+// CUs, and with several frames in flight (sgm_compute_batch, bench.py workloads with several streams) the
+// GPU is full without any pre-pass.
+constexpr int CHAIN_KD = 3;  // a store is taken to be complete when the stores of KD later steps have been issued *and counted*: see chain_publisher_wave
+
+template <int NP, bool PARTIAL>
+__device__ __forceinline__ void chain_publisher_wave(const Geom &g, const SweepArgs &a, int band, int lane, uint32_t *lds)
+{
+    constexpr int PPS = sweep_pps(NP);
+    constexpr int RING = sweep_ring(NP);
+    constexpr int SLOT = sweep_slot_dwords(NP);
+    constexpr int ROLE = 64 * NP;
+    constexpr int STORES_PER_STEP = 3 * PPS * (NP == 4 ? 2 : 1) + 1;  // buf_store<4> = two 64-bit stores; + the progress word
+    static_assert(CHAIN_KD * STORES_PER_STEP <= 63, "vmcnt is a 6-bit counter");
+    const int R = a.R;
+    const int W1 = g.W1, D = g.D;
+    const int NS = (W1 + PPS - 1) / PPS;
+    const int T = NS + 2 * (R - 1);
+    const bool active = !PARTIAL || (2 * NP * lane < D);
+    const int lane_off = active ? 2 * NP * lane : 0;
+    const bool publishes = band + 1 < a.nbands;  // the last band of the sweep has nobody below it
+    // ring R: written by compute wave R - 1 (its `mine`)
+    const uint32_t *const last = lds + lane * NP + R * RING * SLOT;
+    const int row_bytes = W1 * 3 * D * 2;
+    const __amdgpu_buffer_rsrc_t rec = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.bndL + (int64_t)(band + 1) * W1 * 3 * D), 0, row_bytes, 0x00020000);
+    const int voff = lane_off * 2;
+    const int px_bytes = 3 * D * 2;
+    const int pk = a.xdir > 0 ? px_bytes : -px_bytes;
+    const int p0 = a.xdir > 0 ? 0 : (W1 - 1) * px_bytes;
+    uint32_t *const word = a.ctl + 1 + band;
+    if (!publishes) {
+        for (int n = 0; n <= T; n++) wg_barrier();
+        return;
+    }
+    // interval n = the code between barrier n - 1 and barrier n (interval 0 precedes the prologue barrier,
+    // interval T + 1 follows the last barrier).  Compute wave R - 1 finishes its step i (pixels PPS i ..)
+    // with barrier 1 + 2 (R - 1) + i, so those pixels are read here in interval n = i + 2 (R - 1) + 2; their
+    // ring slots are rewritten four steps later.
+    for (int n = 0; n <= T + 1; n++) {
+        const int i = n - 2 * (R - 1) - 2;
+        if (i >= 0 && i < NS) {
+#pragma unroll
+            for (int p = 0; p < PPS; p++) {
+                const int k = PPS * i + p;
+                const uint32_t *s = last + (k % RING) * SLOT;
+                Pack<NP> v[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) lds_load<NP>(v[d], s + d * ROLE);
+                // (a pixel past the row's end: offset past the record, the store is dropped but counted)
+                const int so = k < W1 ? p0 + k * pk : row_bytes;
+#pragma unroll
+                for (int d = 0; d < 3; d++)
+                    if (!PARTIAL || active) buf_store<NP, 16>(v[d], rec, voff, so + d * D * 2);
+            }
+        } else {
+            // no pixels in this interval: the same number of (dropped) stores, so that the count below holds
+            Pack<NP> z;
+            z.fill(0u);
+#pragma unroll
+            for (int p = 0; p < 3 * PPS; p++)
+                if (!PARTIAL || active) buf_store<NP, 16>(z, rec, voff, row_bytes);
+        }
+        // all stores but those of the last KD intervals (this one included) are complete
+        __builtin_amdgcn_s_waitcnt(0x0f70 | ((CHAIN_KD * STORES_PER_STEP) & 15) | (((CHAIN_KD * STORES_PER_STEP) >> 4) << 14));
+        const int done = min(max(PPS * (i - CHAIN_KD + 1), 0), W1);
+        if (lane == 0) __hip_atomic_store(word, (uint32_t)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n <= T) wg_barrier();
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the whole row is in HBM
+    if (lane == 0) __hip_atomic_store(word, (uint32_t)W1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NP, bool PARTIAL, int MODE>
+__global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 128) void k_sweep_chain(Geom g, SweepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    uint32_t *const ticket = lds + (a.R + 1) * sweep_ring(NP) * sweep_slot_dwords(NP);  // one word behind the rings
+    for (;;) {
+        if (threadIdx.x == 0) *ticket = atomicAdd(a.ctl, 1u);
+        wg_barrier();
+        const int band = __builtin_amdgcn_readfirstlane((int)*ticket);
+        // (the next write of the ticket word comes after the 1 + T barriers of the band: every wave has read it by then)
+        if (band >= a.nbands) break;
+        if (wave == a.R) sweep_loader_wave<NP, PARTIAL, true>(g, a, band, lane, lds);
+        else if (wave == a.R + 1) chain_publisher_wave<NP, PARTIAL>(g, a, band, lane, lds);
+        else sweep_compute_wave<NP, PARTIAL, MODE, true>(g, a, band, wave, lane, lds);
     }
 }
 

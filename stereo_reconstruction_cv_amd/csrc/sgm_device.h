@@ -370,16 +370,18 @@ __device__ __forceinline__ void buf_load(Pack<NP> &p, __amdgpu_buffer_rsrc_t rsr
         p.r[3] = v.w;
     }
 }
-template <int NP>
+// AUX: cache policy bits of the store (2 = nt: streaming, the default; 16 = sc1: write-through, agent scope --
+// the chained sweep's hand-off records)
+template <int NP, int AUX = SGM_ST_AUX>
 __device__ __forceinline__ void buf_store(const Pack<NP> &p, __amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes)
 {
     if constexpr (NP == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(p.r[0], rsrc, voff_bytes, soff_bytes, SGM_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(p.r[0], rsrc, voff_bytes, soff_bytes, AUX);
     } else if constexpr (NP == 2) {
         v2u32 v;
         v.x = p.r[0];
         v.y = p.r[1];
-        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff_bytes, soff_bytes, SGM_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff_bytes, soff_bytes, AUX);
 #ifdef SGM_EXPERIMENT_STORE_X4  // ISA study only; never defined in a shipped build
     } else if constexpr (NP == 4) {
         v4u32 v;
@@ -387,7 +389,7 @@ __device__ __forceinline__ void buf_store(const Pack<NP> &p, __amdgpu_buffer_rsr
         v.y = p.r[1];
         v.z = p.r[2];
         v.w = p.r[3];
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff_bytes, soff_bytes, SGM_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff_bytes, soff_bytes, AUX);
 #endif
     } else {
         // Two 64-bit stores, never buffer_store_dwordx4 (root cause found in round 2).
@@ -407,9 +409,9 @@ __device__ __forceinline__ void buf_store(const Pack<NP> &p, __amdgpu_buffer_rsr
         lo.y = p.r[1];
         hi.x = p.r[2];
         hi.y = p.r[3];
-        __builtin_amdgcn_raw_buffer_store_b64(lo, rsrc, voff_bytes, soff_bytes, SGM_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(lo, rsrc, voff_bytes, soff_bytes, AUX);
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_raw_buffer_store_b64(hi, rsrc, voff_bytes + 8, soff_bytes, SGM_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(hi, rsrc, voff_bytes + 8, soff_bytes, AUX);
     }
 }
 

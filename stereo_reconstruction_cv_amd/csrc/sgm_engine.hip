@@ -107,7 +107,8 @@ struct sgm_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int keep_aggr = 0;
     int profile = 0;
-    int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps
+    int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps; 2: chained sweeps, no pre-pass (throughput mode)
+    int chain_wgs = 0;   // schedule 2: workgroups (= bands in flight) per sweep launch; 0 = automatic
     int sweep_rows = 0;  // rows per band of the sweep (0 = automatic)
     int debug = 0;       // timing experiments (SweepArgs::dbg)
     int prepass_rows = 0;  // rows per chunk of the boundary pre-pass (0 = automatic, about 135, a multiple of 8)
@@ -134,6 +135,7 @@ struct sgm_engine {
     DevBuf rmap1, rmap2, rsrc, rdst;    // host-pointer rectification stages
     DevBuf ccount, cpts, crgb, crgb_in; // point compaction
     DevBuf headroom;                    // uint32[2]: max C_true (incl. upstream's running-sum intermediate), max min_d L_r
+    DevBuf chain_ctl, chain_err;        // chained sweeps: ticket + progress words (zeroed before every launch); sticky give-up flag
 
     // profiling
     std::vector<hipEvent_t> events;
@@ -350,6 +352,29 @@ static int launch_sweep(const Geom &g, const SweepArgs &a, int mode, int nbands,
     if (g.NP == 1) return partial ? launch_sweep_np<1, true>(g, a, mode, nbands, st) : launch_sweep_np<1, false>(g, a, mode, nbands, st);
     if (g.NP == 2) return partial ? launch_sweep_np<2, true>(g, a, mode, nbands, st) : launch_sweep_np<2, false>(g, a, mode, nbands, st);
     return partial ? launch_sweep_np<4, true>(g, a, mode, nbands, st) : launch_sweep_np<4, false>(g, a, mode, nbands, st);
+}
+
+// chained sweep (kernels_sweep.h: k_sweep_chain): `wgs` persistent workgroups of R compute waves + loader + publisher
+template <int NP, bool PARTIAL, int MODE>
+static int launch_chain_one(const Geom &g, const SweepArgs &a, int wgs, hipStream_t st)
+{
+    const size_t lds = sweep_lds_bytes(NP, a.R) + 16;  // + the ticket word
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep_chain<NP, PARTIAL, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_sweep_chain<NP, PARTIAL, MODE>), dim3(wgs), dim3((a.R + 2) * 64), lds, st, g, a);
+    return SGM_OK;
+}
+template <int NP, bool PARTIAL>
+static int launch_chain_np(const Geom &g, const SweepArgs &a, int mode, int wgs, hipStream_t st)
+{
+    if (mode == SWEEP_FIRST) return launch_chain_one<NP, PARTIAL, SWEEP_FIRST>(g, a, wgs, st);
+    return launch_chain_one<NP, PARTIAL, SWEEP_ACCUM>(g, a, wgs, st);
+}
+static int launch_chain(const Geom &g, const SweepArgs &a, int mode, int wgs, hipStream_t st)
+{
+    const bool partial = g.D != 128 * g.NP;
+    if (g.NP == 1) return partial ? launch_chain_np<1, true>(g, a, mode, wgs, st) : launch_chain_np<1, false>(g, a, mode, wgs, st);
+    if (g.NP == 2) return partial ? launch_chain_np<2, true>(g, a, mode, wgs, st) : launch_chain_np<2, false>(g, a, mode, wgs, st);
+    return partial ? launch_chain_np<4, true>(g, a, mode, wgs, st) : launch_chain_np<4, false>(g, a, mode, wgs, st);
 }
 
 // rows per band: about 240 bands (one workgroup per CU, most of the 256 CUs busy), bounded by
@@ -640,12 +665,26 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         } else {
             // -- fused schedule: per pass a read-only boundary pre-pass (3 line scans) + one sweep
             const size_t bnd_bytes = (size_t)nbands * g.W1 * 3 * g.D * 2;
+            // Chained schedule (SGM_OPT_SCHEDULE 2, kernels_sweep.h: k_sweep_chain): no pre-pass; the bands of a sweep
+            // hand the state of their last row to each other through the same record.  Only where the fused sweep
+            // runs (the small-D schedule keeps its own kernels) and where there is more than one band.
+            const bool chain = e->schedule == 2 && !rows4 && nbands > 1 && !((e->debug & 2) && g.mode == 1);  // (debug 2: winner-take-all inside the second sweep -- plain schedule only)
             if (nbands > 1) {
                 if ((rc = e->bndL.ensure(bnd_bytes))) return rc;
-                if (npass == 2 && (rc = e->bndL2.ensure(bnd_bytes))) return rc;
-                const size_t st_bytes = (size_t)2 * 3 * g.W1 * g.D * 2;  // ping-pong line state between pre-pass chunks
-                if ((rc = e->pstate.ensure(st_bytes))) return rc;
-                if (npass == 2 && (rc = e->pstate2.ensure(st_bytes))) return rc;
+                if (!chain) {
+                    if (npass == 2 && (rc = e->bndL2.ensure(bnd_bytes))) return rc;
+                    const size_t st_bytes = (size_t)2 * 3 * g.W1 * g.D * 2;  // ping-pong line state between pre-pass chunks
+                    if ((rc = e->pstate.ensure(st_bytes))) return rc;
+                    if (npass == 2 && (rc = e->pstate2.ensure(st_bytes))) return rc;
+                }
+            }
+            const size_t ctl_bytes = ((size_t)(1 + nbands) * 4 + 15) & ~(size_t)15;
+            if (chain) {
+                if ((rc = e->chain_ctl.ensure(ctl_bytes))) return rc;
+                if (!e->chain_err.p) {
+                    if ((rc = e->chain_err.ensure(16))) return rc;
+                    HIP_TRY(hipMemsetAsync(e->chain_err.p, 0, 16, st));
+                }
             }
             // roles of the pre-pass: 0 = predecessor one step earlier in the sweep's x order
             // (x - xdir), 1 = same column, 2 = one step later
@@ -717,7 +756,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             };
             // MODE_HH: the upward pre-pass only reads C, so it runs on the auxiliary stream while the
             // main stream does the downward pre-pass and sweep (memory-bound beside issue-bound work)
-            const bool overlap = npass == 2 && nbands > 1 && !(e->debug & 32);
+            const bool overlap = npass == 2 && nbands > 1 && !(e->debug & 32) && !chain;
             auto fork_prepass_up = [&]() -> int {  // aux stream: upward pre-pass, from "now" on the main stream
                 int rc2;
                 if (!e->aux) {
@@ -771,7 +810,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             for (int pass = 0; pass < npass; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
                 int16_t *bl = (int16_t *)(pass == 0 ? e->bndL.p : e->bndL2.p);
-                if (nbands > 1 && !(overlap && pass == 1)) {
+                if (nbands > 1 && !(overlap && pass == 1) && !chain) {
                     if ((rc = stage_begin(e, pass == 0 ? "prepass_dn" : "prepass_up"))) return rc;
                     const int nl = launch_prepass(xdir, ydir, bl, st);
                     KCHECK();
@@ -785,8 +824,16 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 // winner-take-all: fused into the last path kernel (debug 2), or -- default -- a
                 // separate pass over S with one lane per pixel (k_wta_t)
                 const bool last = pass == npass - 1 && g.mode == 1 && fused_wta && !rows4;
-                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug, 0};
-                if ((rc = stage_begin(e, pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up")))) return rc;
+                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug, nullptr, nullptr, nbands};
+                if (chain) {
+                    a.bndL = (const int16_t *)e->bndL.p;  // one record serves both passes (they follow each other on the stream)
+                    a.ctl = (uint32_t *)e->chain_ctl.p;
+                    a.err = (uint32_t *)e->chain_err.p;
+                    HIP_TRY(hipMemsetAsync(e->chain_ctl.p, 0, ctl_bytes, st));
+                    stage_break(e);
+                }
+                if ((rc = stage_begin(e, chain ? (pass == 0 ? "chain_dn" : "chain_up")
+                                               : (pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up"))))) return rc;
                 // per-row state written by the grouped pre-pass: role-major; by the single-direction kernel (debug 16): band layout
                 const int rmaj = (e->debug & 16) ? 0 : 1;
                 if (rows4 && !(e->debug & 4096)) {
@@ -817,6 +864,13 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     else if (GWs == 16) SGM_ROWS4(16);
                     else SGM_ROWS4(32);
 #undef SGM_ROWS4
+                } else if (chain) {
+                    // workgroups = bands in flight.  A band trails the band above by about 2 (R - 1) + 16 lockstep steps and
+                    // lasts T steps: more than T / lag workgroups would only wait (and hold CUs other frames could use).
+                    const int pps = sweep_pps(g.NP);
+                    const int T = (g.W1 + pps - 1) / pps + 2 * (R - 1), lag = 2 * (R - 1) + 16;
+                    const int wgs = e->chain_wgs > 0 ? e->chain_wgs : std::max(4, (T + lag - 1) / lag);
+                    if ((rc = launch_chain(g, a, pass == 0 ? SWEEP_FIRST : SWEEP_ACCUM, std::min(nbands, wgs), st))) return rc;
                 } else if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) {
                     return rc;
                 }
@@ -1026,7 +1080,7 @@ void sgm_destroy(sgm_engine *e)
     (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->aggr2, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2, &e->pstate, &e->pstate2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
-                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom};
+                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom, &e->chain_ctl, &e->chain_err};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->aux) {
@@ -1050,11 +1104,23 @@ int sgm_set_option(sgm_engine *e, int option, int value)
     if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
     if (option == SGM_OPT_KEEP_AGGR) e->keep_aggr = value ? 1 : 0;
     else if (option == SGM_OPT_PROFILE) e->profile = value ? 1 : 0;
-    else if (option == SGM_OPT_SCHEDULE) e->schedule = value ? 1 : 0;
+    else if (option == SGM_OPT_SCHEDULE) e->schedule = std::max(0, std::min(value, 2));
+    else if (option == SGM_OPT_CHAIN_WGS) e->chain_wgs = std::max(0, value);
     else if (option == SGM_OPT_SWEEP_ROWS) e->sweep_rows = std::max(0, value);
     else if (option == SGM_OPT_DEBUG) e->debug = value;
     else if (option == SGM_OPT_PREPASS_ROWS) e->prepass_rows = std::max(0, value);
     else return set_err(SGM_ERR_INVALID_ARG, "unknown option %d", option);
+    return SGM_OK;
+}
+
+// Chained sweeps bound every wait for another workgroup (kernels_sweep.h: ChainWait); a wait that gave up leaves a
+// sticky flag and wrong results.  Looked at wherever the host synchronises with the engine's stream anyway.
+static int check_chain(sgm_engine *e)
+{
+    if (!e->chain_err.p) return SGM_OK;
+    uint32_t f = 0;
+    HIP_TRY(hipMemcpy(&f, e->chain_err.p, 4, hipMemcpyDeviceToHost));
+    if (f) return set_err(SGM_ERR_HIP, "chained sweep: a workgroup gave up waiting for the band above it (results are invalid)");
     return SGM_OK;
 }
 
@@ -1063,7 +1129,7 @@ int sgm_synchronize(sgm_engine *e)
     if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    return SGM_OK;
+    return check_chain(e);
 }
 
 int sgm_compute_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W, int64_t stride_bytes,
@@ -1259,7 +1325,7 @@ int sgm_compute(sgm_engine *e, const uint8_t *left, const uint8_t *right, int H,
     if ((rc = run_compute(e, (const uint8_t *)e->in_left.p, (const uint8_t *)e->in_right.p, H, W, W, (int16_t *)e->disp_out.p))) return rc;
     HIP_TRY(hipMemcpyAsync(disp_out, e->disp_out.p, npx * 2, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    return SGM_OK;
+    return check_chain(e);
 }
 
 // N independent pairs from / to host memory.  Up to three pairs are in flight: pair i runs on engine
@@ -1463,7 +1529,7 @@ int sgm_get_tap(sgm_engine *e, int tap, void *host_dst, int64_t bytes)
     if (need == 0) return SGM_OK;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(host_dst, src, (size_t)need, hipMemcpyDeviceToHost));
-    return SGM_OK;
+    return check_chain(e);
 }
 
 int sgm_get_headroom(sgm_engine *e, int *max_cost_plus_p2, int *max_delta, int *ok)

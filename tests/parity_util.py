@@ -21,8 +21,10 @@ def params(D, bs, minD=0, mode=0, penalty="notebook", **kw):
     return p
 
 
-def run_hip_with_taps(left, right, p, schedule=1, sweep_rows=0, debug=0, prepass_rows=0):
+def run_hip_with_taps(left, right, p, schedule=1, sweep_rows=0, debug=0, prepass_rows=0, chain_wgs=0):
     eng = Engine(p)
+    if chain_wgs:
+        eng.set_option(_lib.SGM_OPT_CHAIN_WGS, chain_wgs)
     if debug:
         eng.set_option(_lib.SGM_OPT_DEBUG, debug)
     if prepass_rows:
@@ -42,11 +44,11 @@ def run_hip_with_taps(left, right, p, schedule=1, sweep_rows=0, debug=0, prepass
     return out
 
 
-def compare_stages(left, right, p, schedule=1, sweep_rows=0, prepass_rows=0):
+def compare_stages(left, right, p, schedule=1, sweep_rows=0, prepass_rows=0, chain_wgs=0):
     """Returns (report dict stage -> mismatch count, oracle taps)."""
     d, t = O.sgbm_compute(left, right, taps=True, **p)
     t["disp"] = d
-    h = run_hip_with_taps(left, right, p, schedule, sweep_rows, prepass_rows=prepass_rows)
+    h = run_hip_with_taps(left, right, p, schedule, sweep_rows, prepass_rows=prepass_rows, chain_wgs=chain_wgs)
     rep = {}
     for k in ("C", "S", "disp_raw", "disp_median", "disp"):
         if k in h and k in t:

@@ -1,0 +1,56 @@
+"""Chained sweeps (SGM_OPT_SCHEDULE = 2, kernels_sweep.h: k_sweep_chain): the bands of a sweep take the
+state of the row above them from the band above -- through HBM, behind a progress word -- instead of
+from a boundary pre-pass.  Same arithmetic, so every stage tap must equal the oracle's bit for bit
+(upstream's single top-down / bottom-up pass per row: /root/reference/main.ipynb:668),
+for any band height, any number of workgroups in flight (1 = the bands strictly one after the other),
+both modes, full and partial wavefronts, D <= 128 / 256 / 512, and launch after launch on one engine
+(ticket and progress words are reset by the engine before every launch)."""
+import numpy as np
+import pytest
+
+import parity_util as U
+from oracle import oracle as O
+from stereo_reconstruction_cv_amd import _lib, synth
+from stereo_reconstruction_cv_amd.stereo import Engine
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # H, W, D, bs, mode, rows per band
+    (61, 300, 128, 5, 0, 3), (47, 420, 256, 7, 1, 2), (90, 200, 80, 3, 1, 4), (33, 1100, 512, 3, 1, 1),
+    (130, 228, 128, 5, 1, 9), (58, 500, 192, 5, 0, 11), (75, 400, 256, 7, 1, 5), (29, 640, 160, 5, 0, 7),
+    (40, 700, 384, 3, 1, 3),
+]
+
+
+@pytest.mark.parametrize("wgs", [0, 1, 2, 5, 64])
+@pytest.mark.parametrize("H,W,D,bs,mode,rows", SHAPES)
+def test_chained_sweeps_bit_exact(H, W, D, bs, mode, rows, wgs):
+    l, r, _ = synth.make_pair(H, W, D, 4000 + H + D)
+    p = U.params(D, bs, 0, mode, speckleWindowSize=30, speckleRange=2)
+    rep, t, h = U.compare_stages(l, r, p, schedule=2, sweep_rows=rows, chain_wgs=wgs)
+    assert t["headroom_ok"]
+    bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
+    assert not bad, f"wgs={wgs}: " + "\n".join(bad)
+
+
+def test_back_to_back_frames_on_one_engine():
+    """ticket / progress words are per launch: a second and third frame (different images, then a
+    different shape) on the same engine must not see anything of the first."""
+    p = U.params(256, 7, 0, 1, speckleWindowSize=30, speckleRange=2)
+    eng = Engine(p)
+    eng.set_option(_lib.SGM_OPT_SCHEDULE, 2)
+    eng.set_option(_lib.SGM_OPT_SWEEP_ROWS, 4)
+    for (H, W, seed) in ((50, 420, 1), (50, 420, 2), (37, 500, 3), (50, 420, 1)):
+        l, r, _ = synth.make_pair(H, W, 256, seed)
+        want = O.sgbm_compute(l, r, **p)
+        got = eng.compute_host(l, r)
+        assert np.array_equal(got, want), (H, W, seed, int((got != want).sum()))
+
+
+def test_small_disparity_ranges_keep_their_own_schedule():
+    """D <= 64 runs the lane-grouped kernels whatever the schedule option says."""
+    l, r, _ = synth.make_pair(60, 300, 32, 9)
+    p = U.params(32, 5, 0, 1, speckleWindowSize=30, speckleRange=2)
+    rep, t, h = U.compare_stages(l, r, p, schedule=2)
+    assert not [k for k, n in rep.items() if n]
