@@ -58,6 +58,8 @@ WORKLOADS = {
     "c3c5x3": (2160, 3840, 256, 7, 1, 3, True, "three concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on three HIP streams (+ reproject)"),
     "c3c5x4": (2160, 3840, 256, 7, 1, 4, True, "four concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on four HIP streams (+ reproject)"),
     "c3c5x6": (2160, 3840, 256, 7, 1, 6, True, "six concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on six HIP streams (+ reproject)"),
+    "c3c5x8": (2160, 3840, 256, 7, 1, 8, True, "eight 3840x2160 D=256 bs=7 MODE_HH pairs per step (+ reproject)"),
+    "c3c5x12": (2160, 3840, 256, 7, 1, 12, True, "twelve 3840x2160 D=256 bs=7 MODE_HH pairs per step (+ reproject)"),
     "nb": (2160, 3840, 16, 11, 0, 1, True, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
     "tiny": (96, 480, 64, 7, 1, 2, True, "96x480 D=64 MODE_HH x2 (launcher rehearsal only, not a BASELINE config)"),
 }
@@ -194,7 +196,9 @@ def main():
     ap.add_argument("--concurrent", type=int, default=0,
                     help="engines (HIP streams) working on different pairs at the same time; 0 = workload default")
     ap.add_argument("--schedule", type=int, default=1, help="0: one kernel per path direction, 1: fused sweeps behind a pre-pass, 2: chained sweeps (no pre-pass)")
-    ap.add_argument("--chain-wgs", type=int, default=0, help="schedule 2: workgroups per sweep launch (0 = automatic)")
+    ap.add_argument("--chain-wgs", type=int, default=0, help="schedule 2: workgroups per frame of a sweep launch (0 = automatic)")
+    ap.add_argument("--batch", action="store_true",
+                    help="hand all pairs of a step to sgm_pipeline_batch_device of ONE engine (schedule 2: one chained sweep launch per pass for all of them)")
     ap.add_argument("--debug", type=int, default=0, help="SGM_OPT_DEBUG bit mask (A/B measurements; include/sgm_hip.h)")
     ap.add_argument("--prepass-rows", type=int, default=0, help="rows per chunk of the boundary pre-pass (0 = automatic)")
     ap.add_argument("--sweep-rows", type=int, default=0, help="rows per band of the fused sweeps (0 = automatic)")
@@ -272,7 +276,7 @@ def main():
 
     # `nconc` engines = HIP streams; pair i of a step runs on engine i % nconc, so independent
     # pairs overlap on the GPU (each engine owns its own device buffers)
-    nconc = max(1, min(args.concurrent or ppg, ppg))
+    nconc = 1 if args.batch else max(1, min(args.concurrent or ppg, ppg))
     engines = []
     for _ in range(nconc):
         e = Engine(p, device=local_rank)
@@ -293,6 +297,12 @@ def main():
         """enqueue every pair of this rank on its engine, then collect the HIP-event stage times"""
         acc = []
         n = len(lefts)
+        if args.batch:
+            ptrs = lambda ts: [t.data_ptr() for t in ts] if ts is not None else None
+            eng.pipeline_batch_device(ptrs(lefts), ptrs(rights), H, W, W, Q if with_xyz else None, ptrs(disps),
+                                      ptrs(dispfs) if with_xyz else None, ptrs(xyzs) if with_xyz else None)
+            st = eng.stage_times()       # (synchronises; the first pair's stages + the joint sweep launches)
+            return [st] * n
         for i0 in range(0, n, nconc):
             group = range(i0, min(i0 + nconc, n))
             for i in group:  # enqueue on every stream first ...
@@ -461,7 +471,7 @@ def main():
                                " (BENCH_REHEARSE: ranks share GPUs, numbers meaningless)" if rehearse else ""),
         "config": {"workload": f"{args.workload}: {desc}", "height": H, "width": W, "numDisparities": D,
                    "blockSize": bs, "mode": "MODE_HH" if mode else "MODE_SGBM", "pairs_per_gpu_per_step": ppg,
-                   "global_pairs_per_step": ppg * world, "streams_per_gpu": nconc,
+                   "global_pairs_per_step": ppg * world, "streams_per_gpu": nconc, "batch_entry": bool(args.batch),
                    "schedule": ("one kernel per direction", "fused sweeps", "chained sweeps")[args.schedule],
                    **({"debug_mask": args.debug} if args.debug else {}),
                    "world_size": dist.get_world_size() if world > 1 else 1,

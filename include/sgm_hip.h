@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SGM_ABI_VERSION 1
+#define SGM_ABI_VERSION 3   /* 2: sgm_get_headroom, SGM_OPT_PREPASS_ROWS (round 2); 3: sgm_pipeline_batch_device, SGM_OPT_CHAIN_WGS, schedule 2 */
 
 typedef enum {
     SGM_OK = 0,
@@ -193,6 +193,14 @@ int sgm_remap_linear_u8_device(sgm_engine *e, const void *d_src, int sH, int sW,
 int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W,
                         int64_t stride_bytes, const double Q[16], void *d_disp_i16,
                         void *d_disp_f32, void *d_xyz_f32);
+/* The driver cell over N resident pairs (BASELINE config 4: a batch of pairs per GPU; main.ipynb:780-797 once per pair),
+ * throughput mode: arrays of N device pointers (d_disp_f32 / d_xyz_f32 may be NULL).  With SGM_OPT_SCHEDULE = 2 the
+ * pairs share ONE chained sweep launch per pass (groups of up to 16 pairs on internal engines: about 12 GB of device
+ * memory per 4K D=256 pair of a group); otherwise pair after pair.  Results equal N calls of sgm_pipeline_device.
+ * Asynchronous: sgm_synchronize(e) waits for all of it. */
+int sgm_pipeline_batch_device(sgm_engine *e, int N, const void *const *d_left, const void *const *d_right, int H, int W,
+                              int64_t stride_bytes, const double Q[16], void *const *d_disp_i16,
+                              void *const *d_disp_f32, void *const *d_xyz_f32);
 int sgm_synchronize(sgm_engine *e);
 
 /* per-stage HIP-event timing of the last compute (requires SGM_OPT_PROFILE = 1) */

@@ -24,7 +24,7 @@ EXPORTS = (
     "sgm_reproject", "sgm_valid_mask", "sgm_get_tap", "sgm_get_headroom", "sgm_median3x3", "sgm_filter_speckles", "sgm_compact_points",
     "sgm_compact_points_device", "sgm_compute_device",
     "sgm_disp_to_float_device", "sgm_reproject_device", "sgm_valid_mask_device",
-    "sgm_pipeline_device", "sgm_synchronize", "sgm_get_stage_times", "sgm_algorithmic_bytes",
+    "sgm_pipeline_device", "sgm_pipeline_batch_device", "sgm_synchronize", "sgm_get_stage_times", "sgm_algorithmic_bytes",
     "sgm_init_undistort_rectify_map", "sgm_init_undistort_rectify_map_device",
     "sgm_remap_linear_u8", "sgm_remap_linear_u8_device",
 )
@@ -45,6 +45,9 @@ class LibraryMissing(RuntimeError):
     pass
 
 
+ABI_VERSION = 3   # include/sgm_hip.h: SGM_ABI_VERSION this binding was written against
+
+
 _lib = None
 
 
@@ -58,6 +61,11 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C stereo_reconstruction_cv_amd/csrc` (there is no CPU fallback)")
     L = C.CDLL(LIB_PATH)
+    L.sgm_abi_version.restype = C.c_int
+    if L.sgm_abi_version() != ABI_VERSION:      # a stale build: say so instead of an AttributeError at bind time
+        raise LibraryMissing(
+            f"{LIB_PATH} has ABI version {L.sgm_abi_version()}, this package needs {ABI_VERSION}: rebuild it "
+            "(`make -C stereo_reconstruction_cv_amd/csrc`)")
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     pp = C.POINTER(SgmParams)
     L.sgm_abi_version.restype = i32
@@ -84,6 +92,7 @@ def load():
     L.sgm_reproject_device.argtypes = [vp, vp, i32, i32, vp, i32, vp]
     L.sgm_valid_mask_device.argtypes = [vp, vp, vp, i64, vp]
     L.sgm_pipeline_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, vp, vp]
+    L.sgm_pipeline_batch_device.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, vp, vp, vp]
     L.sgm_synchronize.argtypes = [vp]
     L.sgm_get_stage_times.argtypes = [vp, C.POINTER(SgmStageTimes)]
     L.sgm_algorithmic_bytes.argtypes = [pp, i32, i32, i32]

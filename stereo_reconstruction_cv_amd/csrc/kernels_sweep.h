@@ -37,9 +37,22 @@ struct SweepArgs {
     int keepS;
     int dbg;  // timing experiments only (results become wrong): 64 = loader wave skips its HBM loads
     // chained schedule only (k_sweep_chain): bndL is then the record the bands hand to each other
-    uint32_t *ctl;  // [0] band ticket, [1 + b] = pixels of band b's last row that have reached HBM; zeroed before every launch
-    uint32_t *err;  // sticky, never reset by a launch: set when a bounded wait gave up
+    uint32_t *ctl;   // [0] ticket, [1 + f * nbands + b] = pixels of the last row of band b of frame f that have reached HBM;
+                     // zeroed before every launch
+    uint32_t *prog;  // (set by the kernel) progress words of the frame a workgroup is working on = ctl + 1 + f * nbands
+    uint32_t *err;   // sticky, never reset by a launch: set when a bounded wait gave up
     int nbands;
+};
+
+// Frames of one chained launch (sgm_pipeline_batch_device: several pairs per launch, so that the GPU is full although
+// one frame's chain keeps only T / LAG workgroups busy).  Tickets go round the frames: ticket t = band t / nf of frame t % nf.
+constexpr int CHAIN_MAX_FRAMES = 16;
+struct ChainFrames {
+    int nf;
+    const int16_t *C[CHAIN_MAX_FRAMES];
+    int16_t *S[CHAIN_MAX_FRAMES];
+    int16_t *bnd[CHAIN_MAX_FRAMES];   // hand-off record [band][x][3][D] of each frame
+    uint32_t *hr[CHAIN_MAX_FRAMES];   // headroom record of each frame
 };
 
 constexpr int SWEEP_MAX_ROWS = 11;  // compute waves per workgroup (768 threads = 3 waves per SIMD -> 168 VGPRs per lane)
@@ -173,7 +186,7 @@ __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs
     const int p0 = a.xdir > 0 ? 0 : (W1 - 1) * px_bytes;
     ChainWait cw;
     if (CHAIN && has_prev) {
-        cw.word = a.ctl + band;  // = ctl[1 + (band - 1)]
+        cw.word = a.prog + band - 1;
         cw.err = a.err;
     }
     // FULL = every pixel of the block exists: no guards, so hipcc can count the loads in flight
@@ -534,7 +547,7 @@ __device__ __forceinline__ void chain_publisher_wave(const Geom &g, const SweepA
     const int px_bytes = 3 * D * 2;
     const int pk = a.xdir > 0 ? px_bytes : -px_bytes;
     const int p0 = a.xdir > 0 ? 0 : (W1 - 1) * px_bytes;
-    uint32_t *const word = a.ctl + 1 + band;
+    uint32_t *const word = a.prog + band;
     if (!publishes) {
         for (int n = 0; n <= T; n++) wg_barrier();
         return;
@@ -577,8 +590,12 @@ __device__ __forceinline__ void chain_publisher_wave(const Geom &g, const SweepA
     if (lane == 0) __hip_atomic_store(word, (uint32_t)W1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// (The winner-take-all inside the second sweep, SWEEP_LAST, was measured here too -- 12 pairs per launch: 3.25 ms per
+// pair against 2.47 + 0.74 for SWEEP_ACCUM + k_wta_t: it saves 2 V of traffic and loses it again to the vector units --
+// and is not instantiated.)
+constexpr int CHAIN_MAX_ROWS = 12;  // 12 compute waves + loader + publisher = 14 waves: three compute waves on every SIMD
 template <int NP, bool PARTIAL, int MODE>
-__global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 128) void k_sweep_chain(Geom g, SweepArgs a)
+__global__ __launch_bounds__(CHAIN_MAX_ROWS * 64 + 128) void k_sweep_chain(Geom g, SweepArgs a, ChainFrames fr)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -587,9 +604,15 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 128) void k_sweep_chain(Geom 
     for (;;) {
         if (threadIdx.x == 0) *ticket = atomicAdd(a.ctl, 1u);
         wg_barrier();
-        const int band = __builtin_amdgcn_readfirstlane((int)*ticket);
+        const int tk = __builtin_amdgcn_readfirstlane((int)*ticket);
         // (the next write of the ticket word comes after the 1 + T barriers of the band: every wave has read it by then)
-        if (band >= a.nbands) break;
+        if (tk >= a.nbands * fr.nf) break;
+        const int f = tk % fr.nf, band = tk / fr.nf;
+        a.C = fr.C[f];
+        a.S = fr.S[f];
+        a.bndL = fr.bnd[f];
+        a.prog = a.ctl + 1 + f * a.nbands;
+        g.hr = fr.hr[f];
         if (wave == a.R) sweep_loader_wave<NP, PARTIAL, true>(g, a, band, lane, lds);
         else if (wave == a.R + 1) chain_publisher_wave<NP, PARTIAL>(g, a, band, lane, lds);
         else sweep_compute_wave<NP, PARTIAL, MODE, true>(g, a, band, wave, lane, lds);

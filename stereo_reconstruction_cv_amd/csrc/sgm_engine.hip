@@ -109,12 +109,16 @@ struct sgm_engine {
     int profile = 0;
     int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps; 2: chained sweeps, no pre-pass (throughput mode)
     int chain_wgs = 0;   // schedule 2: workgroups (= bands in flight) per sweep launch; 0 = automatic
+    bool plan_chain = false;  // what PH_PRE of the last compute decided: chained sweeps? band height, bands
+    int plan_R = 0, plan_nbands = 0;
     int sweep_rows = 0;  // rows per band of the sweep (0 = automatic)
     int debug = 0;       // timing experiments (SweepArgs::dbg)
     int prepass_rows = 0;  // rows per chunk of the boundary pre-pass (0 = automatic, about 135, a multiple of 8)
     // sgm_compute_batch: up to three pairs in flight = this engine + two peers (own stream and device
     // buffers), each with page-locked staging buffers for the images and the disparity map
     sgm_engine *peer = nullptr, *peer2 = nullptr;
+    std::vector<sgm_engine *> group;      // sgm_pipeline_batch_device: the other engines of a chained group (own streams and buffers)
+    hipEvent_t ev_group = nullptr;
     HostBuf pin_left, pin_right, pin_disp;
     hipEvent_t ev_done = nullptr;
 
@@ -356,25 +360,34 @@ static int launch_sweep(const Geom &g, const SweepArgs &a, int mode, int nbands,
 
 // chained sweep (kernels_sweep.h: k_sweep_chain): `wgs` persistent workgroups of R compute waves + loader + publisher
 template <int NP, bool PARTIAL, int MODE>
-static int launch_chain_one(const Geom &g, const SweepArgs &a, int wgs, hipStream_t st)
+static int launch_chain_one(const Geom &g, const SweepArgs &a, const ChainFrames &fr, int wgs, hipStream_t st)
 {
     const size_t lds = sweep_lds_bytes(NP, a.R) + 16;  // + the ticket word
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweep_chain<NP, PARTIAL, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_sweep_chain<NP, PARTIAL, MODE>), dim3(wgs), dim3((a.R + 2) * 64), lds, st, g, a);
+    hipLaunchKernelGGL((k_sweep_chain<NP, PARTIAL, MODE>), dim3(wgs), dim3((a.R + 2) * 64), lds, st, g, a, fr);
     return SGM_OK;
 }
 template <int NP, bool PARTIAL>
-static int launch_chain_np(const Geom &g, const SweepArgs &a, int mode, int wgs, hipStream_t st)
+static int launch_chain_np(const Geom &g, const SweepArgs &a, const ChainFrames &fr, int mode, int wgs, hipStream_t st)
 {
-    if (mode == SWEEP_FIRST) return launch_chain_one<NP, PARTIAL, SWEEP_FIRST>(g, a, wgs, st);
-    return launch_chain_one<NP, PARTIAL, SWEEP_ACCUM>(g, a, wgs, st);
+    if (mode == SWEEP_FIRST) return launch_chain_one<NP, PARTIAL, SWEEP_FIRST>(g, a, fr, wgs, st);
+    return launch_chain_one<NP, PARTIAL, SWEEP_ACCUM>(g, a, fr, wgs, st);
 }
-static int launch_chain(const Geom &g, const SweepArgs &a, int mode, int wgs, hipStream_t st)
+static int launch_chain(const Geom &g, const SweepArgs &a, const ChainFrames &fr, int mode, int wgs, hipStream_t st)
 {
     const bool partial = g.D != 128 * g.NP;
-    if (g.NP == 1) return partial ? launch_chain_np<1, true>(g, a, mode, wgs, st) : launch_chain_np<1, false>(g, a, mode, wgs, st);
-    if (g.NP == 2) return partial ? launch_chain_np<2, true>(g, a, mode, wgs, st) : launch_chain_np<2, false>(g, a, mode, wgs, st);
-    return partial ? launch_chain_np<4, true>(g, a, mode, wgs, st) : launch_chain_np<4, false>(g, a, mode, wgs, st);
+    if (g.NP == 1) return partial ? launch_chain_np<1, true>(g, a, fr, mode, wgs, st) : launch_chain_np<1, false>(g, a, fr, mode, wgs, st);
+    if (g.NP == 2) return partial ? launch_chain_np<2, true>(g, a, fr, mode, wgs, st) : launch_chain_np<2, false>(g, a, fr, mode, wgs, st);
+    return partial ? launch_chain_np<4, true>(g, a, fr, mode, wgs, st) : launch_chain_np<4, false>(g, a, fr, mode, wgs, st);
+}
+// workgroups of a chained launch over nf frames: a band trails the band above by about 2 (R - 1) + 16 lockstep steps and
+// lasts T steps, so a frame keeps about T / lag workgroups busy; more would only wait (and hold CUs)
+static int chain_window(const Geom &g, int R, int nbands, int nf, int override_wgs)
+{
+    const int pps = sweep_pps(g.NP);
+    const int T = (g.W1 + pps - 1) / pps + 2 * (R - 1), lag = 2 * (R - 1) + 16;
+    const int per_frame = override_wgs > 0 ? override_wgs : std::max(4, (T + lag - 1) / lag);
+    return (int)std::min<int64_t>({(int64_t)per_frame * nf, (int64_t)nbands * nf, 256});
 }
 
 // rows per band: about 240 bands (one workgroup per CU, most of the 256 CUs busy), bounded by
@@ -382,10 +395,13 @@ static int launch_chain(const Geom &g, const SweepArgs &a, int mode, int wgs, hi
 // a band's step time is set by its busiest SIMD (3 waves with 9 rows + loader as with 11 + loader), so
 // taller bands cost the sweep nothing, write and read 18 % less boundary state and leave more CUs to the
 // upward pre-pass that runs beside the downward sweep (4K: 11.05 -> 10.9 ms; MODE_SGBM: no gain).
-static int sweep_rows_for(const Geom &g, int override_rows, int npass)
+// Chained schedule: bands are not tied to the number of CUs (a window of workgroups slides over them), so the tallest
+// band the workgroup can hold: 12 rows = three compute waves on every SIMD, and the least hand-off traffic (3 / R volumes).
+static int sweep_rows_for(const Geom &g, int override_rows, int npass, bool chained = false)
 {
-    int maxR = SWEEP_MAX_ROWS;
-    while (maxR > 1 && sweep_lds_bytes(g.NP, maxR) > 160 * 1024) maxR--;
+    int maxR = chained ? CHAIN_MAX_ROWS : SWEEP_MAX_ROWS;
+    while (maxR > 1 && sweep_lds_bytes(g.NP, maxR) + 16 > 160 * 1024) maxR--;
+    if (chained && override_rows <= 0) return std::max(1, std::min(maxR, g.H));
     const int bands = npass == 2 ? 200 : 240;
     int R = override_rows > 0 ? override_rows : (g.H + bands - 1) / bands;
     if (override_rows <= 0) R = std::max(R, 4);
@@ -440,8 +456,14 @@ __global__ void k_fill_i16(int16_t *p, int64_t n, int16_t v)
     if (i < n) p[i] = v;
 }
 
+// Phases of one compute.  A single pair runs them all; the batch entry with chained sweeps
+// (sgm_pipeline_batch_device) runs PH_PRE of every pair, then ONE sweep launch per pass for all pairs, then PH_POST
+// of every pair.
+enum { PH_PRE = 1 /* features, block cost, MODE_SGBM's fifth path beside the sweep */, PH_MID = 2 /* pre-pass + sweeps */,
+       PH_POST = 4 /* the rest */, PH_ALL = 7 };
+
 static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_right, int H, int W,
-                       int64_t stride, int16_t *d_disp)
+                       int64_t stride, int16_t *d_disp, int phases = PH_ALL)
 {
     if (!e || !d_left || !d_right || !d_disp) return set_err(SGM_ERR_INVALID_ARG, "null pointer");
     if (H <= 0 || W < 2 || stride < W) return set_err(SGM_ERR_INVALID_ARG, "bad shape H=%d W=%d stride=%lld", H, W, (long long)stride);
@@ -451,18 +473,25 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
     if (rc) return rc;
     const Geom &g = e->g;
     hipStream_t st = e->stream;
-    e->nstages = 0;
-    e->nevents = 0;
-    e->last_end_ev = -1;
+    const bool do_pre = (phases & PH_PRE) != 0, do_mid = (phases & PH_MID) != 0, do_post = (phases & PH_POST) != 0;
+    if (do_pre) {
+        e->nstages = 0;
+        e->nevents = 0;
+        e->last_end_ev = -1;
+        e->plan_chain = false;
+    } else {
+        stage_break(e);
+    }
     const int64_t npx = (int64_t)H * W;
     const unsigned nb_px = (unsigned)((npx + 255) / 256);
 
     int16_t *raw = (int16_t *)e->disp_raw.p, *med = (int16_t *)e->disp_med.p;
-    HIP_TRY(hipMemsetAsync(e->headroom.p, 0, 8, st));  // headroom record of this compute (sgm_get_headroom)
+    if (do_pre) HIP_TRY(hipMemsetAsync(e->headroom.p, 0, 8, st));  // headroom record of this compute (sgm_get_headroom)
 
     if (g.W1 <= 0) {
         // no column can be matched: the whole map is invalid (upstream early-out), then median
         // and speckle act on a constant image
+        if (phases != PH_ALL) return set_err(SGM_ERR_INVALID_ARG, "phased compute on a frame without matchable columns");
         if ((rc = stage_begin(e, "fill_invalid"))) return rc;
         hipLaunchKernelGGL(k_fill_i16, dim3(nb_px), dim3(256), 0, st, raw, npx, (int16_t)g.invalid_scaled);
         KCHECK();
@@ -474,14 +503,14 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         uint2 *wta = (uint2 *)e->wta.p;
 
         // -- features
-        if ((rc = stage_begin(e, "features"))) return rc;
-        {
+        if (do_pre) {
+            if ((rc = stage_begin(e, "features"))) return rc;
             dim3 grid((W + 255) / 256, H, 2), block(256);
             hipLaunchKernelGGL(k_features, grid, block, 0, st, d_left, d_right, stride, H, W, g.ftzero, (uint2 *)e->lrec.p,
                                (uint8_t *)e->rplanes.p);
             KCHECK();
+            if ((rc = stage_end(e, 1))) return rc;
         }
-        if ((rc = stage_end(e, 1))) return rc;
 
         // -- horizontal box sum of the pixel cost
         // -- horizontal box sum of the pixel cost (rows y0 .. y1-1), vertical box sum -> block cost
@@ -587,7 +616,15 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         const bool rows4 = GWs <= ((e->debug & 8192) ? 16 : 32) && e->sweep_rows <= 0 &&
                            (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
         const int npass = g.mode == 1 ? 2 : 1;
-        const int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows, npass);
+        // Chained schedule (SGM_OPT_SCHEDULE 2, kernels_sweep.h: k_sweep_chain): no pre-pass; the bands of a sweep hand the
+        // state of their last row to each other.  Only where the fused sweep runs (the small-D schedule keeps its own
+        // kernels), where there is more than one band, and not with debug 2 (winner-take-all inside the second sweep).
+        bool chain = e->schedule == 2 && !rows4 && !((e->debug & 2) && g.mode == 1);
+        int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows, npass, chain);
+        if (chain && (H + R - 1) / R <= 1) {
+            chain = false;
+            R = sweep_rows_for(g, e->sweep_rows, npass, false);
+        }
         const int nbands = (H + R - 1) / R;
         // Narrow frames (fewer than ~1.5 lines per SIMD) are bound by the latency of one wave's
         // instruction stream: there the single-direction kernel with one wave per (line, role) -- three
@@ -599,7 +636,9 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // streams was built and measured in round 2: the overlapped kernels only slow each other down --
         // cost_box 1.17 -> 2.75 ms, prepass_dn 2.05 -> 3.19 ms, frame 11.97 against 11.90 ms -- this phase
         // of the frame is bound by HBM bandwidth, not by the order of its launches.  DESIGN.md 4.4.)
-        if (byte_cost) {
+        if (!do_pre) {
+            // (the cost stage belongs to PH_PRE)
+        } else if (byte_cost) {
             if ((rc = stage_begin(e, "cost_pix"))) return rc;
             launch_pix(0, H, st);
             KCHECK();
@@ -634,6 +673,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         }  // int16 pipeline
 
         if (e->schedule == 0) {
+            if (phases != PH_ALL) return set_err(SGM_ERR_INVALID_ARG, "phased compute needs the fused schedules");
             // -- v1 schedule: one kernel per direction, vertical-ish first, horizontal last (WTA)
             struct Dir { int rx, ry; const char *name; };
             static const Dir down[3] = {{0, 1, "path_S"}, {1, 1, "path_SE"}, {-1, 1, "path_SW"}};
@@ -665,10 +705,6 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         } else {
             // -- fused schedule: per pass a read-only boundary pre-pass (3 line scans) + one sweep
             const size_t bnd_bytes = (size_t)nbands * g.W1 * 3 * g.D * 2;
-            // Chained schedule (SGM_OPT_SCHEDULE 2, kernels_sweep.h: k_sweep_chain): no pre-pass; the bands of a sweep
-            // hand the state of their last row to each other through the same record.  Only where the fused sweep
-            // runs (the small-D schedule keeps its own kernels) and where there is more than one band.
-            const bool chain = e->schedule == 2 && !rows4 && nbands > 1 && !((e->debug & 2) && g.mode == 1);  // (debug 2: winner-take-all inside the second sweep -- plain schedule only)
             if (nbands > 1) {
                 if ((rc = e->bndL.ensure(bnd_bytes))) return rc;
                 if (!chain) {
@@ -679,6 +715,12 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 }
             }
             const size_t ctl_bytes = ((size_t)(1 + nbands) * 4 + 15) & ~(size_t)15;
+            if (do_pre) {
+                e->plan_chain = chain;
+                e->plan_R = R;
+                e->plan_nbands = nbands;
+            }
+            if (phases != PH_ALL && !chain) return set_err(SGM_ERR_INVALID_ARG, "phased compute needs the chained schedule");
             if (chain) {
                 if ((rc = e->chain_ctl.ensure(ctl_bytes))) return rc;
                 if (!e->chain_err.p) {
@@ -793,6 +835,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             if (two_vol) {
                 if ((rc = e->aggr2.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
                 S2 = (int16_t *)e->aggr2.p;
+            }
+            if (two_vol && do_pre) {
                 if (!e->aux) {
                     HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
                     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -807,7 +851,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 HIP_TRY(hipEventRecord(e->ev_join, e->aux));
             }
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
-            for (int pass = 0; pass < npass; pass++) {
+            for (int pass = 0; pass < npass && do_mid; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
                 int16_t *bl = (int16_t *)(pass == 0 ? e->bndL.p : e->bndL2.p);
                 if (nbands > 1 && !(overlap && pass == 1) && !chain) {
@@ -824,9 +868,15 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 // winner-take-all: fused into the last path kernel (debug 2), or -- default -- a
                 // separate pass over S with one lane per pixel (k_wta_t)
                 const bool last = pass == npass - 1 && g.mode == 1 && fused_wta && !rows4;
-                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug, nullptr, nullptr, nbands};
+                SweepArgs a{ydir, xdir, R, C, S, (const int16_t *)bl, wta, e->keep_aggr, e->debug, nullptr, nullptr, nullptr, nbands};
+                ChainFrames fr;
                 if (chain) {
-                    a.bndL = (const int16_t *)e->bndL.p;  // one record serves both passes (they follow each other on the stream)
+                    // one record serves both passes (they follow each other on the stream)
+                    fr.nf = 1;
+                    fr.C[0] = C;
+                    fr.S[0] = S;
+                    fr.bnd[0] = (int16_t *)e->bndL.p;
+                    fr.hr[0] = g.hr;
                     a.ctl = (uint32_t *)e->chain_ctl.p;
                     a.err = (uint32_t *)e->chain_err.p;
                     HIP_TRY(hipMemsetAsync(e->chain_ctl.p, 0, ctl_bytes, st));
@@ -865,18 +915,14 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     else SGM_ROWS4(32);
 #undef SGM_ROWS4
                 } else if (chain) {
-                    // workgroups = bands in flight.  A band trails the band above by about 2 (R - 1) + 16 lockstep steps and
-                    // lasts T steps: more than T / lag workgroups would only wait (and hold CUs other frames could use).
-                    const int pps = sweep_pps(g.NP);
-                    const int T = (g.W1 + pps - 1) / pps + 2 * (R - 1), lag = 2 * (R - 1) + 16;
-                    const int wgs = e->chain_wgs > 0 ? e->chain_wgs : std::max(4, (T + lag - 1) / lag);
-                    if ((rc = launch_chain(g, a, pass == 0 ? SWEEP_FIRST : SWEEP_ACCUM, std::min(nbands, wgs), st))) return rc;
+                    if ((rc = launch_chain(g, a, fr, pass == 0 ? SWEEP_FIRST : SWEEP_ACCUM, chain_window(g, R, nbands, 1, e->chain_wgs), st))) return rc;
                 } else if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) {
                     return rc;
                 }
                 KCHECK();
                 if ((rc = stage_end(e, 1))) return rc;
             }
+            if (!do_post) return SGM_OK;
             if (two_vol) {
                 HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
                 stage_break(e);
@@ -1016,6 +1062,27 @@ static int run_reproject(sgm_engine *e, const float *d_disp, int H, int W, const
     return SGM_OK;
 }
 
+// float scaling + reprojection of one pair on its engine's stream (shared by the single-pair and the batch entry)
+static int run_float_xyz(sgm_engine *e, const int16_t *di, int H, int W, const double Q[16], void *d_disp_f32, void *d_xyz_f32)
+{
+    const int64_t n = (int64_t)H * W;
+    int rc;
+    if (!d_disp_f32 && !d_xyz_f32) return SGM_OK;
+    if (d_xyz_f32) {
+        if (!Q) return set_err(SGM_ERR_INVALID_ARG, "Q is null");
+        QMat q;
+        memcpy(q.q, Q, sizeof(q.q));
+        if ((rc = stage_begin(e, "float_xyz"))) return rc;
+        hipLaunchKernelGGL(k_float_xyz, dim3((W + 255) / 256, H), dim3(256), 0, e->stream, di, H, W, q,
+                           (float *)d_disp_f32, (float *)d_xyz_f32);
+        KCHECK();
+        return stage_end(e, 1);
+    }
+    if ((rc = stage_begin(e, "to_float"))) return rc;
+    if ((rc = run_to_float(e, di, n, (float *)d_disp_f32))) return rc;
+    return stage_end(e, 1);
+}
+
 // ---- exported C ABI -------------------------------------------------------------------------------
 extern "C" {
 
@@ -1096,6 +1163,8 @@ void sgm_destroy(sgm_engine *e)
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->peer) sgm_destroy(e->peer);
     if (e->peer2) sgm_destroy(e->peer2);
+    for (sgm_engine *q : e->group) sgm_destroy(q);
+    if (e->ev_group) (void)hipEventDestroy(e->ev_group);
     delete e;
 }
 
@@ -1292,22 +1361,125 @@ int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, 
         di = (int16_t *)e->disp_out.p;
     }
     if ((rc = run_compute(e, (const uint8_t *)d_left, (const uint8_t *)d_right, H, W, stride_bytes, di))) return rc;
-    if (!d_disp_f32 && !d_xyz_f32) return SGM_OK;
-    if (d_xyz_f32) {
-        // float scaling + reprojection in one launch (the float map is stored only if asked for)
-        if (!Q) return set_err(SGM_ERR_INVALID_ARG, "Q is null");
-        QMat q;
-        memcpy(q.q, Q, sizeof(q.q));
-        if ((rc = stage_begin(e, "float_xyz"))) return rc;
-        hipLaunchKernelGGL(k_float_xyz, dim3((W + 255) / 256, H), dim3(256), 0, e->stream, (const int16_t *)di, H, W, q,
-                           (float *)d_disp_f32, (float *)d_xyz_f32);
-        KCHECK();
-        if ((rc = stage_end(e, 1))) return rc;
-        return SGM_OK;
+    // float scaling + reprojection in one launch (the float map is stored only if asked for)
+    return run_float_xyz(e, di, H, W, Q, d_disp_f32, d_xyz_f32);
+}
+
+// N pairs resident in device memory, throughput mode.  With the chained schedule (SGM_OPT_SCHEDULE 2 on `e`) and a
+// configuration the fused sweeps cover, the pairs go through the frame in lockstep of its phases: cost stage of every pair
+// (each on the stream of one of up to CHAIN_MAX_FRAMES internal engines), then ONE chained sweep launch per pass over all
+// pairs of the group on `e`'s stream, then the winner-take-all and the epilogue of every pair.  One frame's chain of bands
+// keeps only about 50 workgroups busy; a group of 6 or more fills the GPU, and no boundary pre-pass runs at all.
+// Otherwise: pair after pair on `e` (the schedule `e` is set to).  Results equal N calls of sgm_pipeline_device.
+// Asynchronous like sgm_pipeline_device: returns when everything is enqueued; sgm_synchronize(e) waits for all of it.
+int sgm_pipeline_batch_device(sgm_engine *e, int N, const void *const *d_left, const void *const *d_right, int H, int W,
+                              int64_t stride_bytes, const double Q[16], void *const *d_disp_i16, void *const *d_disp_f32,
+                              void *const *d_xyz_f32)
+{
+    if (!e || N <= 0 || !d_left || !d_right || !d_disp_i16) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    // can this configuration run chained ?  (decided by the first pair's PH_PRE; the same for every pair of the batch)
+    bool joint = e->schedule == 2 && N > 1;
+    if (joint) {
+        while ((int)e->group.size() < std::min(N, CHAIN_MAX_FRAMES) - 1) {
+            sgm_engine *q = nullptr;
+            if ((rc = sgm_create(&e->params, e->device, nullptr, &q))) return rc;
+            e->group.push_back(q);
+        }
+        if (!e->ev_group) HIP_TRY(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
     }
-    if ((rc = stage_begin(e, "to_float"))) return rc;
-    if ((rc = run_to_float(e, di, n, (float *)d_disp_f32))) return rc;
-    if ((rc = stage_end(e, 1))) return rc;
+    for (int i0 = 0; i0 < N; i0 += CHAIN_MAX_FRAMES) {
+        const int n = std::min(N - i0, CHAIN_MAX_FRAMES);
+        std::vector<sgm_engine *> eng(n);
+        for (int k = 0; k < n; k++) {
+            sgm_engine *q = (k == 0 || !joint) ? e : e->group[k - 1];
+            eng[k] = q;
+            if (q != e) {
+                q->keep_aggr = 0;
+                q->profile = 0;
+                q->schedule = e->schedule;
+                q->sweep_rows = e->sweep_rows;
+                q->debug = e->debug;
+                q->chain_wgs = e->chain_wgs;
+                if (!q->ev_done) HIP_TRY(hipEventCreateWithFlags(&q->ev_done, hipEventDisableTiming));
+            }
+        }
+        if (joint && n > 1) {
+            // the peers start where `e`'s stream stands now (the caller's inputs may have been produced on it)
+            HIP_TRY(hipEventRecord(e->ev_group, e->stream));
+            for (int k = 1; k < n; k++) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, e->ev_group, 0));
+            for (int k = 0; k < n && joint; k++) {
+                if ((rc = run_compute(eng[k], (const uint8_t *)d_left[i0 + k], (const uint8_t *)d_right[i0 + k], H, W, stride_bytes,
+                                      (int16_t *)d_disp_i16[i0 + k], PH_PRE))) {
+                    if (k == 0 && !e->plan_chain) {  // not a configuration for chained sweeps: nothing is enqueued yet but pair 0's cost stage
+                        joint = false;
+                        break;
+                    }
+                    return rc;
+                }
+            }
+        }
+        if (!joint || n == 1) {
+            joint = false;
+            for (int k = 0; k < n; k++) {
+                const int i = i0 + k;
+                if ((rc = sgm_pipeline_device(e, d_left[i], d_right[i], H, W, stride_bytes, Q, d_disp_i16[i],
+                                              d_disp_f32 ? d_disp_f32[i] : nullptr, d_xyz_f32 ? d_xyz_f32[i] : nullptr)))
+                    return rc;
+            }
+            continue;
+        }
+        // ---- the sweeps of all n pairs: one launch per pass on e's stream, behind every pair's cost stage
+        const Geom &g = e->g;
+        const int R = e->plan_R, nbands = e->plan_nbands, npass = g.mode == 1 ? 2 : 1;
+        const size_t ctl_bytes = ((size_t)(1 + (size_t)n * nbands) * 4 + 15) & ~(size_t)15;
+        if ((rc = e->chain_ctl.ensure(ctl_bytes))) return rc;
+        for (int k = 1; k < n; k++) {
+            HIP_TRY(hipEventRecord(eng[k]->ev_done, eng[k]->stream));
+            HIP_TRY(hipStreamWaitEvent(e->stream, eng[k]->ev_done, 0));
+        }
+        stage_break(e);
+        ChainFrames fr;
+        fr.nf = n;
+        for (int k = 0; k < n; k++) {
+            fr.C[k] = (const int16_t *)eng[k]->cost.p;
+            fr.S[k] = (int16_t *)eng[k]->aggr.p;
+            fr.bnd[k] = (int16_t *)eng[k]->bndL.p;
+            fr.hr[k] = eng[k]->g.hr;
+        }
+        for (int pass = 0; pass < npass; pass++) {
+            const int ydir = pass == 0 ? 1 : -1;
+            SweepArgs a{ydir, ydir, R, nullptr, nullptr, nullptr, nullptr, 0, e->debug, (uint32_t *)e->chain_ctl.p, nullptr,
+                        (uint32_t *)e->chain_err.p, nbands};
+            HIP_TRY(hipMemsetAsync(e->chain_ctl.p, 0, ctl_bytes, e->stream));
+            stage_break(e);
+            if ((rc = stage_begin(e, pass == 0 ? "chain_dn" : "chain_up"))) return rc;
+            if ((rc = launch_chain(g, a, fr, pass == 0 ? SWEEP_FIRST : SWEEP_ACCUM,
+                                   chain_window(g, R, nbands, n, e->chain_wgs), e->stream)))
+                return rc;
+            KCHECK();
+            if ((rc = stage_end(e, 1))) return rc;
+        }
+        HIP_TRY(hipEventRecord(e->ev_group, e->stream));
+        // ---- the rest of every pair on its own stream (memory-bound kernels of different pairs side by side)
+        for (int k = 0; k < n; k++) {
+            const int i = i0 + k;
+            if (k > 0) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, e->ev_group, 0));
+            if ((rc = run_compute(eng[k], (const uint8_t *)d_left[i], (const uint8_t *)d_right[i], H, W, stride_bytes,
+                                  (int16_t *)d_disp_i16[i], PH_POST)))
+                return rc;
+            if ((rc = run_float_xyz(eng[k], (const int16_t *)d_disp_i16[i], H, W, Q, d_disp_f32 ? d_disp_f32[i] : nullptr,
+                                    d_xyz_f32 ? d_xyz_f32[i] : nullptr)))
+                return rc;
+        }
+        // e's stream ends behind everything the group did
+        for (int k = 1; k < n; k++) {
+            HIP_TRY(hipEventRecord(eng[k]->ev_done, eng[k]->stream));
+            HIP_TRY(hipStreamWaitEvent(e->stream, eng[k]->ev_done, 0));
+        }
+        stage_break(e);
+    }
     return SGM_OK;
 }
 
@@ -1345,10 +1517,64 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
     HIP_TRY(hipSetDevice(e->device));
     const size_t npx = (size_t)H * W;
     int rc;
+    if (e->schedule == 2 && N > 1) {
+        // throughput mode: groups of up to 12 pairs through sgm_pipeline_batch_device (one chained sweep launch per pass
+        // and group); inputs and results of a group staged in device buffers of the group's engines
+        const int GN = 12;
+        std::vector<const void *> dl(GN), dr(GN);
+        std::vector<void *> dd(GN), df(GN), dx(GN);
+        for (int i0 = 0; i0 < N; i0 += GN) {
+            const int n = std::min(GN, N - i0);
+            while ((int)e->group.size() < n - 1) {
+                sgm_engine *q = nullptr;
+                if ((rc = sgm_create(&e->params, e->device, nullptr, &q))) return rc;
+                e->group.push_back(q);
+            }
+            for (int k = 0; k < n; k++) {
+                sgm_engine *q = k == 0 ? e : e->group[k - 1];
+                const size_t i = (size_t)(i0 + k);
+                if ((rc = q->in_left.ensure(npx)) || (rc = q->in_right.ensure(npx)) || (rc = q->disp_out.ensure(npx * 2))) return rc;
+                if (xyz_out && ((rc = q->f32.ensure(npx * 4)) || (rc = q->xyz.ensure(npx * 12)))) return rc;
+                HIP_TRY(hipMemcpyAsync(q->in_left.p, lefts + i * npx, npx, hipMemcpyHostToDevice, e->stream));
+                HIP_TRY(hipMemcpyAsync(q->in_right.p, rights + i * npx, npx, hipMemcpyHostToDevice, e->stream));
+                dl[k] = q->in_left.p;
+                dr[k] = q->in_right.p;
+                dd[k] = q->disp_out.p;
+                df[k] = xyz_out ? q->f32.p : nullptr;
+                dx[k] = xyz_out ? q->xyz.p : nullptr;
+            }
+            if ((rc = sgm_pipeline_batch_device(e, n, dl.data(), dr.data(), H, W, W, Q16, dd.data(), xyz_out ? df.data() : nullptr,
+                                                xyz_out ? dx.data() : nullptr))) {
+                (void)hipStreamSynchronize(e->stream);
+                return rc;
+            }
+            for (int k = 0; k < n; k++) {
+                const size_t i = (size_t)(i0 + k);
+                HIP_TRY(hipMemcpyAsync(disps_out + i * npx, dd[k], npx * 2, hipMemcpyDeviceToHost, e->stream));
+                if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out + i * npx * 3, dx[k], npx * 12, hipMemcpyDeviceToHost, e->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(e->stream));
+        }
+        return check_chain(e);
+    }
     const int neng = std::min(N, 3);
     if (neng > 1 && !e->peer && (rc = sgm_create(&e->params, e->device, nullptr, &e->peer))) return rc;
     if (neng > 2 && !e->peer2 && (rc = sgm_create(&e->params, e->device, nullptr, &e->peer2))) return rc;
     sgm_engine *eng[3] = {e, e->peer, e->peer2};
+    const int saved_keep = e->keep_aggr, saved_profile = e->profile;
+    // every exit drains the streams of all engines (copies into / out of the page-locked staging buffers and kernels may
+    // still be in flight when an error is returned) and gives the caller's engine its own options back
+    struct Drain {
+        sgm_engine **eng;
+        int n, keep, prof;
+        ~Drain()
+        {
+            for (int k = 0; k < n; k++)
+                if (eng[k]) (void)hipStreamSynchronize(eng[k]->stream);
+            eng[0]->keep_aggr = keep;
+            eng[0]->profile = prof;
+        }
+    } drain{eng, neng, saved_keep, saved_profile};
     for (int k = 0; k < neng; k++) {
         sgm_engine *q = eng[k];
         q->keep_aggr = 0;

@@ -198,6 +198,19 @@ class Engine:
             qp = Q.ctypes.data
         _check(self._L.sgm_pipeline_device(self._h, d_left, d_right, H, W, stride, qp, d_disp, d_dispf, d_xyz))
 
+    def pipeline_batch_device(self, d_lefts, d_rights, H: int, W: int, stride: int, Q: np.ndarray | None,
+                              d_disps, d_dispfs=None, d_xyzs=None) -> None:
+        """N resident pairs in throughput mode (sgm_pipeline_batch_device): sequences of N device addresses.
+        With SGM_OPT_SCHEDULE = 2 the pairs share one chained sweep launch per pass.  Asynchronous."""
+        n = len(d_lefts)
+        arr = lambda xs: (C.c_void_p * n)(*[int(x) for x in xs]) if xs is not None else None
+        qp = None
+        if Q is not None:
+            Q = np.ascontiguousarray(Q, np.float64)
+            qp = Q.ctypes.data
+        a, b, c, d, f = arr(d_lefts), arr(d_rights), arr(d_disps), arr(d_dispfs), arr(d_xyzs)
+        _check(self._L.sgm_pipeline_batch_device(self._h, n, a, b, H, W, stride, qp, c, d, f))
+
     def disp_to_float_device(self, d_disp: int, n: int, d_out: int) -> None:
         _check(self._L.sgm_disp_to_float_device(self._h, d_disp, n, d_out))
 

@@ -54,3 +54,42 @@ def test_small_disparity_ranges_keep_their_own_schedule():
     p = U.params(32, 5, 0, 1, speckleWindowSize=30, speckleRange=2)
     rep, t, h = U.compare_stages(l, r, p, schedule=2)
     assert not [k for k, n in rep.items() if n]
+
+
+@pytest.mark.parametrize("H,W,D,bs,mode,rows,N", [(47, 420, 256, 7, 1, 2, 3), (61, 300, 128, 5, 0, 3, 5), (40, 520, 256, 5, 0, 4, 2),
+                                                   (33, 300, 96, 3, 1, 1, 18), (52, 700, 512, 3, 1, 5, 4)])
+def test_batch_entry_shares_one_chained_launch(H, W, D, bs, mode, rows, N):
+    """sgm_pipeline_batch_device: N resident pairs, one chained sweep launch per pass for a group of up to 16 pairs
+    (18 pairs = two groups), every pair's cost stage / epilogue on an engine of its own.  Each map, float map and XYZ image
+    must equal the oracle's for its own pair -- frames of a group share nothing but the ticket counter."""
+    import torch
+    p = U.params(D, bs, 0, mode, speckleWindowSize=30, speckleRange=2)
+    Q = synth.default_Q(W)
+    pairs = [synth.make_pair(H, W, D, 700 + i)[:2] for i in range(N)]
+    dev = torch.device("cuda", 0)
+    dl = [torch.from_numpy(a).to(dev) for a, _ in pairs]
+    dr = [torch.from_numpy(b).to(dev) for _, b in pairs]
+    dd = [torch.empty((H, W), dtype=torch.int16, device=dev) for _ in range(N)]
+    df = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(N)]
+    dx = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(N)]
+    torch.cuda.synchronize()
+    eng = Engine(p)
+    eng.set_option(_lib.SGM_OPT_SCHEDULE, 2)
+    eng.set_option(_lib.SGM_OPT_SWEEP_ROWS, rows)
+    ptr = lambda ts: [t.data_ptr() for t in ts]
+    for rep in range(2):      # twice: the second call reuses the group's engines and control words
+        for t in dd:
+            t.fill_(-7)
+        torch.cuda.synchronize()
+        eng.pipeline_batch_device(ptr(dl), ptr(dr), H, W, W, Q, ptr(dd), ptr(df), ptr(dx))
+        eng.synchronize()
+        for i, (a, b) in enumerate(pairs):
+            want = O.sgbm_compute(a, b, **p)
+            got = dd[i].cpu().numpy()
+            assert np.array_equal(got, want), (rep, i, int((got != want).sum()))
+            wf = O.disp_to_float(want)
+            assert np.array_equal(df[i].cpu().numpy().view(np.uint32), wf.view(np.uint32)), (rep, i)
+            ref = O.reproject(wf, Q)
+            x = dx[i].cpu().numpy()
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(x), fin) and np.array_equal(x[fin], ref[fin]), (rep, i)
