@@ -1,5 +1,5 @@
 """Randomised parity sweep (fixed seeds): every constructor argument of cv2.StereoSGBM_create that
-the path honours, odd shapes, both modes, both schedules -- all stage taps bit-exact against the
+the path honours, odd shapes, both modes, all three schedules -- all stage taps bit-exact against the
 oracle.  Cases that leave the int16 no-overflow regime are skipped, not compared."""
 import numpy as np
 import pytest
@@ -46,11 +46,14 @@ def test_random_parameters_bit_exact(seed):
         assert not h["headroom"]["ok"], (h["headroom"], t["max_cost_plus_p2"], t["max_delta"])
         pytest.skip("input leaves the int16 no-overflow regime (the engine's headroom record says so too)")
     t["disp"] = want
-    for schedule in (1, 0):
+    for schedule in (1, 0, 2):
         # (sweep_rows: band height; prepass_rows: chunk height of the pre-pass -- a value also selects the
-        # fused three-role pre-pass kernel on these narrow frames, 0 leaves the engine's own choice)
-        h = U.run_hip_with_taps(l, r, p, schedule=schedule, sweep_rows=[0, 1, 2, 4][seed % 4] if schedule else 0,
-                                prepass_rows=[0, 3, 11, 0, 64][seed % 5] if schedule else 0)
+        # fused three-role pre-pass kernel on these narrow frames, 0 leaves the engine's own choice;
+        # schedule 2 = chained sweeps: band heights that give several bands, 1 .. many workgroups in flight)
+        h = U.run_hip_with_taps(l, r, p, schedule=schedule,
+                                sweep_rows=([0, 1, 2, 4][seed % 4] if schedule == 1 else [1, 2, 3, 5][seed % 4]) if schedule else 0,
+                                prepass_rows=[0, 3, 11, 0, 64][seed % 5] if schedule == 1 else 0,
+                                chain_wgs=[0, 1, 2, 7][seed % 4] if schedule == 2 else 0)
         bad = [U.describe_mismatch(k, h[k], t[k]) for k in ("C", "S", "disp_raw", "disp_median", "disp")
                if k in h and k in t and not np.array_equal(h[k], t[k])]
         if not U.headroom_equal(h, t):
