@@ -12,18 +12,23 @@ Frames are sharded by rank with no data-path collective (weak scaling); the time
 bracketed by barrier + synchronize on both sides and the maximum over ranks is reported.  Rank 0
 prints ONE JSON line.
 
---ingest rank0: rank 0 owns every frame of the step; each step scatters the u8 pairs to their
-ranks, computes, and gathers the int16 disparities (and XYZ when the workload reprojects) back
-over torch.distributed ("nccl" = RCCL over xGMI), all inside the timed region
-(stereo_reconstruction_cv_amd/dist.py).  Default "resident": every rank generates its own
-frames before the timed region; after the timed region an N > 1 run still pushes one batch
-through the scatter/compute/gather path and reports whether it reproduced the resident results
-("rccl_ingest_check"), so the collective path is exercised on hardware by the default command.
+Default workload "c3c5x12": a batch of twelve 3840x2160 pairs per GPU and step, D=256, blockSize=7,
+MODE_HH (8 paths) + LR check + sub-pixel + median + speckle + reprojection to XYZ (the union of
+BASELINE.json configs[2] and configs[4]), in THROUGHPUT MODE: chained sweeps without a boundary
+pre-pass, all pairs of the step through sgm_pipeline_batch_device (one sweep launch per pass for the
+whole batch).  The single-pair latency of the same configuration (pre-pass schedule, one pair per
+step: workload "c3c5") rides along as `latency_mode` at N = 1.  The other configs are selectable
+with --workload and are parity-test cases (tests/test_gpu_configs.py runs every one of them at full
+size against the oracle).
 
-Default workload "c3c5": 3840x2160, D=256, blockSize=7, MODE_HH (8 paths) + LR check +
-sub-pixel + median + speckle + reprojection to XYZ, i.e. the union of BASELINE.json configs[2]
-and configs[4]; the other configs are selectable with --workload and are parity-test cases
-(tests/test_gpu_configs.py runs every one of them at full size against the oracle).
+--ingest rank0: rank 0 owns every frame; scatter of the u8 pairs, compute, gather of the int16
+disparities (and XYZ when the workload reprojects) over torch.distributed ("nccl" = RCCL over xGMI)
+run as a pipeline inside the timed region (stereo_reconstruction_cv_amd/dist.py: IngestPipeline --
+the gather of step k and the scatter of step k + 2 beside the compute of step k + 1, every transfer
+of a scatter / gather posted as one batch so that rank 0's links work at the same time).  The default
+("resident") N > 1 run times that path too, after its own timed region and over the same number of
+steps, and reports it as `ingest_rank0` (with a check that the gathered results equal the resident
+ones) -- under a watchdog and a try/except: whatever happens there, the headline line is printed.
 """
 from __future__ import annotations
 
@@ -34,46 +39,54 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0       # what a plain float4 copy reaches on it (same guide): the practical ceiling
 
 NB = dict(disp12MaxDiff=1, preFilterCap=63, uniquenessRatio=10, speckleWindowSize=100, speckleRange=32)
 
 WORKLOADS = {
-    # name: (H, W, D, blockSize, mode, pairs per GPU per step, reproject, description)
-    "c1": (720, 1280, 64, 5, 0, 1, False, "1280x720 D=64 bs=5 5-path (BASELINE configs[0])"),
-    "c2": (2160, 3840, 128, 7, 0, 1, False, "3840x2160 D=128 bs=7 5-path (configs[1])"),
-    "c3": (2160, 3840, 256, 7, 1, 1, False, "3840x2160 D=256 bs=7 8-path (configs[2])"),
-    "c4": (1080, 1920, 128, 7, 0, 8, False, "8x 1920x1080 D=128 bs=7 5-path per GPU (configs[3]: 64 frames over 8 GPUs)"),
-    "c5": (2160, 3840, 256, 7, 0, 1, True, "3840x2160 D=256 bs=7 5-path + reproject (configs[4])"),
-    "c3c5": (2160, 3840, 256, 7, 1, 1, True,
-             "3840x2160 D=256 bs=7 MODE_HH 8-path + LR + subpixel + median + speckle + reprojectImageTo3D"),
-    "c3c5x2": (2160, 3840, 256, 7, 1, 2, True,
-               "two concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on two HIP streams (+ reproject)"),
-    "c3c5x3": (2160, 3840, 256, 7, 1, 3, True, "three concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on three HIP streams (+ reproject)"),
-    "c3c5x4": (2160, 3840, 256, 7, 1, 4, True, "four concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on four HIP streams (+ reproject)"),
-    "c3c5x6": (2160, 3840, 256, 7, 1, 6, True, "six concurrent 3840x2160 D=256 bs=7 MODE_HH pairs per step on six HIP streams (+ reproject)"),
-    "c3c5x8": (2160, 3840, 256, 7, 1, 8, True, "eight 3840x2160 D=256 bs=7 MODE_HH pairs per step (+ reproject)"),
-    "c3c5x12": (2160, 3840, 256, 7, 1, 12, True, "twelve 3840x2160 D=256 bs=7 MODE_HH pairs per step (+ reproject)"),
-    "nb": (2160, 3840, 16, 11, 0, 1, True, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
-    "tiny": (96, 480, 64, 7, 1, 2, True, "96x480 D=64 MODE_HH x2 (launcher rehearsal only, not a BASELINE config)"),
+    # name: (H, W, D, blockSize, mode, pairs per GPU per step, reproject, schedule, batch entry, description)
+    "c1": (720, 1280, 64, 5, 0, 1, False, 1, False, "1280x720 D=64 bs=5 5-path (BASELINE configs[0])"),
+    "c1x8": (720, 1280, 64, 5, 0, 8, False, 1, False, "8x 1280x720 D=64 bs=5 5-path per step on eight HIP streams"),
+    "c2": (2160, 3840, 128, 7, 0, 1, False, 1, False, "3840x2160 D=128 bs=7 5-path (configs[1])"),
+    "c3": (2160, 3840, 256, 7, 1, 1, False, 1, False, "3840x2160 D=256 bs=7 8-path (configs[2])"),
+    "c4": (1080, 1920, 128, 7, 0, 8, False, 1, False, "8x 1920x1080 D=128 bs=7 5-path per GPU (configs[3]: 64 frames over 8 GPUs)"),
+    "c5": (2160, 3840, 256, 7, 0, 1, True, 1, False, "3840x2160 D=256 bs=7 5-path + reproject (configs[4])"),
+    "c3c5": (2160, 3840, 256, 7, 1, 1, True, 1, False,
+             "3840x2160 D=256 bs=7 MODE_HH 8-path + LR + subpixel + median + speckle + reprojectImageTo3D, one pair (latency mode)"),
+    "c3c5x2": (2160, 3840, 256, 7, 1, 2, True, 1, False, "two concurrent 4K D=256 MODE_HH pairs per step on two HIP streams (+ reproject)"),
+    "c3c5x3": (2160, 3840, 256, 7, 1, 3, True, 1, False, "three concurrent 4K D=256 MODE_HH pairs per step on three HIP streams (+ reproject)"),
+    "c3c5x6": (2160, 3840, 256, 7, 1, 6, True, 2, True, "batch of six 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject)"),
+    "c3c5x12": (2160, 3840, 256, 7, 1, 12, True, 2, True,
+                "batch of twelve 3840x2160 D=256 bs=7 MODE_HH 8-path pairs per step (+ LR + subpixel + median + speckle + "
+                "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch"),
+    "c5x12": (2160, 3840, 256, 7, 0, 12, True, 2, True, "batch of twelve 4K D=256 5-path pairs per step + reproject, throughput mode"),
+    "c4t": (1080, 1920, 128, 7, 0, 16, False, 2, True, "batch of sixteen 1920x1080 D=128 5-path pairs per step, throughput mode"),
+    "nb": (2160, 3840, 16, 11, 0, 1, True, 1, False, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
+    "tiny": (96, 480, 64, 7, 1, 2, True, 1, False, "96x480 D=64 MODE_HH x2 (launcher rehearsal only, not a BASELINE config)"),
+    "tinyt": (96, 480, 128, 7, 1, 3, True, 2, True, "96x480 D=128 MODE_HH x3, throughput mode (launcher rehearsal only)"),
 }
+DEFAULT_WORKLOAD = "c3c5x12"
 
 # stage (HIP-event bracket inside the engine) -> kernel that runs in it, for the roofline record
 STAGE_KERNEL = {
     "chain_dn": "k_sweep_chain<NP,*,SWEEP_FIRST>", "chain_up": "k_sweep_chain<NP,*,SWEEP_ACCUM>",
     "sweep_dn": "k_sweep<NP,*,SWEEP_FIRST>", "sweep_up": "k_sweep<NP,*,SWEEP_ACCUM>", "sweep_up_wta": "k_sweep<NP,*,SWEEP_LAST>",
     "prepass_dn": "k_prepass3<NP,*>", "prepass_up": "k_prepass3<NP,*>", "path_W_wta": "k_rows_g<64,NP,*,PATH_LAST>",
-    "path_W": "k_rows_g<GW,NP,*,PATH_ACCUM>", "wta": "k_wta_t", "cost_pix": "k_pix<NP>", "cost_box": "k_box_u8<R,NP>",
+    "path_W": "k_rows_g<GW,NP,*,PATH_FIRST|ACCUM>", "wta": "k_wta_t", "cost_pix": "k_pix<NP>", "cost_box": "k_box_u8<R,NP>",
     "cost_hsum": "k_hsum<NP,RS>", "cost_vsum": "k_vsum_ring<SH2,NW>", "features": "k_features", "select_lr": "k_select",
     "median3": "k_median3", "speckle": "k_ccl_*", "to_float": "k_disp_to_float", "reproject": "k_reproject",
     "post": "k_post_*", "float_xyz": "k_float_xyz",
 }
+# stages that one launch runs for ALL pairs of a step (batch entry); every other stage runs once per pair
+JOINT_STAGES = ("chain_dn", "chain_up")
 
 
 def sgbm_params(D, bs, mode):
@@ -92,14 +105,30 @@ def source_stamp() -> str:
     return h.hexdigest()[:16]
 
 
-def min_traffic_model(stage: str, V: int, R: int, HW: int, mode: int) -> int | None:
-    """Bytes a launch of this design has to move at least (used for roofline.achieved when no PMC
-    record of the current kernels is committed).  V = 2*H*W1*D; R = rows per sweep band."""
+def floor_bytes(V: int, HW: int, mode: int, with_xyz: bool) -> int:
+    """The least HBM traffic one pair costs in ANY schedule of this design (stated in DESIGN.md 4.2), the
+    denominator of `traffic_over_floor`.  V = 2 H W1 D bytes (one int16 volume), HW = pixels.
+      per-pixel cost as bytes: written + read once                          1   V  (2 x V/2)
+      block cost C: written once, read once per pass                        1 + passes   V
+      S: MODE_HH  written, read + rewritten, read by the winner-take-all    4   V
+         MODE_SGBM written by the sweep, read by the fifth path (+ WTA)     2   V
+      images in, features, WTA records, disparity maps, speckle labels ...  about 40 bytes per pixel
+      float map + XYZ                                                       16 bytes per pixel
+    -> MODE_HH 8 V, MODE_SGBM 6 V (+ the per-pixel terms)."""
+    passes = 2 if mode == 1 else 1
+    return V * (1 + 1 + passes + (4 if mode == 1 else 2)) + 40 * HW + (16 * HW if with_xyz else 0)
+
+
+def model_traffic(stage: str, V: int, R: int, HW: int, mode: int, D: int) -> int | None:
+    """Bytes ONE pair's share of a stage has to move in the schedule that ran (used for roofline.achieved when no
+    PMC record of the current kernels is committed).  R = rows per sweep band."""
     bnd = 3 * V // max(R, 1)
+    two_vol = mode == 0 and D <= 128     # the fifth path writes a volume of its own, added by the winner-take-all
     return {
+        "chain_dn": 2 * V + 2 * bnd, "chain_up": 3 * V + 2 * bnd,
         "sweep_dn": 2 * V + bnd, "sweep_up": 3 * V + bnd, "sweep_up_wta": 2 * V + bnd,
         "prepass_dn": 3 * V + bnd, "prepass_up": 3 * V + bnd,
-        "path_W_wta": 2 * V, "path_W": 3 * V, "wta": V + 8 * HW,
+        "path_W_wta": 2 * V, "path_W": 2 * V if two_vol else 3 * V, "wta": (2 * V if two_vol else V) + 8 * HW,
         "cost_pix": V // 2 + 14 * HW, "cost_box": V // 2 + V, "cost_hsum": V + 14 * HW, "cost_vsum": 2 * V,
     }.get(stage)
 
@@ -148,6 +177,8 @@ def self_launch(n: int, argv: list[str]) -> int:
     rc = p.wait()
     if line:
         print(line)
+        if '"error": "timed out (watchdog)' in line:
+            rc = 0      # the ranks left through the ingest watchdog; the headline line is complete
     elif rc == 0:
         rc = 1
         sys.stderr.write("bench.py: the ranks produced no JSON line\n")
@@ -159,7 +190,7 @@ class MockEngine:
     launcher, rendezvous, sharding, timing and JSON plumbing can run on a box without a GPU.  The
     JSON line says so in `data`; no number from it means anything."""
 
-    def __init__(self, p, device=0):
+    def __init__(self, p, device=0, stream=None):
         self.p = p
 
     def set_option(self, *_):
@@ -174,6 +205,9 @@ class MockEngine:
     def pipeline_device(self, *a):
         time.sleep(0.002)
 
+    def pipeline_batch_device(self, lefts, *a):
+        time.sleep(0.002 * len(lefts))
+
     def stage_times(self):
         return [("sweep_dn", 1.0, 1), ("cost_pix", 0.5, 1), ("_wall", 1.5, 0)]
 
@@ -184,22 +218,24 @@ class MockEngine:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--ingest", default="resident", choices=("resident", "rank0"),
-                    help="rank0: frames start on rank 0; scatter / gather over torch.distributed inside the timed step")
+                    help="rank0: frames start on rank 0; scatter / compute / gather pipeline over torch.distributed inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-mode", action="store_true", help="skip the single-pair latency measurement that rides along at N = 1")
+    ap.add_argument("--no-ingest-leg", action="store_true", help="N > 1, resident: skip the timed rank-0 ingest leg after the timed region")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline runs (0 = auto)")
     ap.add_argument("--verify", action="store_true", help="also run the oracle on the full frame and compare")
     ap.add_argument("--stages", action="store_true", help="print the per-stage HIP-event table to stderr")
     ap.add_argument("--concurrent", type=int, default=0,
                     help="engines (HIP streams) working on different pairs at the same time; 0 = workload default")
-    ap.add_argument("--schedule", type=int, default=1, help="0: one kernel per path direction, 1: fused sweeps behind a pre-pass, 2: chained sweeps (no pre-pass)")
+    ap.add_argument("--schedule", type=int, default=-1,
+                    help="0: one kernel per path direction, 1: fused sweeps behind a pre-pass, 2: chained sweeps (no pre-pass); -1 = workload default")
+    ap.add_argument("--batch", type=int, default=-1, help="1: all pairs of a step through sgm_pipeline_batch_device of ONE engine; 0: one engine call per pair; -1 = workload default")
     ap.add_argument("--chain-wgs", type=int, default=0, help="schedule 2: workgroups per frame of a sweep launch (0 = automatic)")
-    ap.add_argument("--batch", action="store_true",
-                    help="hand all pairs of a step to sgm_pipeline_batch_device of ONE engine (schedule 2: one chained sweep launch per pass for all of them)")
-    ap.add_argument("--debug", type=int, default=0, help="SGM_OPT_DEBUG bit mask (A/B measurements; include/sgm_hip.h)")
+    ap.add_argument("--debug", type=int, default=0, help="SGM_OPT_DEBUG bit mask (A/B measurements; csrc/sgm_debug.h)")
     ap.add_argument("--prepass-rows", type=int, default=0, help="rows per chunk of the boundary pre-pass (0 = automatic)")
     ap.add_argument("--sweep-rows", type=int, default=0, help="rows per band of the fused sweeps (0 = automatic)")
     args = ap.parse_args()
@@ -243,12 +279,13 @@ def main():
 
     if mock:
         Engine = MockEngine
-        OPT_PROFILE = OPT_SCHEDULE = 0
+        OPT = dict(PROFILE=0, SCHEDULE=0, DEBUG=0, PREPASS_ROWS=0, SWEEP_ROWS=0, CHAIN_WGS=0)
     else:
         import stereo_reconstruction_cv_amd as cv
         from stereo_reconstruction_cv_amd import _lib
         Engine = cv.Engine
-        OPT_PROFILE, OPT_SCHEDULE = _lib.SGM_OPT_PROFILE, _lib.SGM_OPT_SCHEDULE
+        OPT = dict(PROFILE=_lib.SGM_OPT_PROFILE, SCHEDULE=_lib.SGM_OPT_SCHEDULE, DEBUG=_lib.SGM_OPT_DEBUG,
+                   PREPASS_ROWS=_lib.SGM_OPT_PREPASS_ROWS, SWEEP_ROWS=_lib.SGM_OPT_SWEEP_ROWS, CHAIN_WGS=_lib.SGM_OPT_CHAIN_WGS)
 
     def sync():
         if not mock:
@@ -256,7 +293,9 @@ def main():
 
     alloc = torch.zeros if mock else torch.empty   # (the mock engine writes nothing)
 
-    H, W, D, bs, mode, ppg, with_xyz, desc = WORKLOADS[args.workload]
+    H, W, D, bs, mode, ppg, with_xyz, wl_schedule, wl_batch, desc = WORKLOADS[args.workload]
+    schedule = wl_schedule if args.schedule < 0 else args.schedule
+    batch = wl_batch if args.batch < 0 else bool(args.batch)
     p = sgbm_params(D, bs, mode)
     Q = synth.default_Q(W)
 
@@ -266,7 +305,9 @@ def main():
         seeds = [1234 + i for i in range(ppg * world)] if rank == 0 else []
     else:
         seeds = [1234 + rank * ppg + i for i in range(ppg)]
-    pairs = [synth.make_pair(H, W, D, seed=s)[:2] for s in seeds]
+    nuniq = min(len(seeds), 4)          # (four different images are plenty; generating one 4K pair costs the host a second)
+    uniq = [synth.make_pair(H, W, D, seed=s)[:2] for s in seeds[:nuniq]]
+    pairs = [uniq[i % nuniq] for i in range(len(seeds))]
     d_left = [torch.from_numpy(a).to(dev) for a, _ in pairs]
     d_right = [torch.from_numpy(b).to(dev) for _, b in pairs]
     d_disp = [alloc((H, W), dtype=torch.int16, device=dev) for _ in range(ppg)]
@@ -274,76 +315,53 @@ def main():
     d_xyz = [alloc((H, W, 3), dtype=torch.float32, device=dev) for _ in range(ppg)] if with_xyz else None
     sync()
 
-    # `nconc` engines = HIP streams; pair i of a step runs on engine i % nconc, so independent
-    # pairs overlap on the GPU (each engine owns its own device buffers)
-    nconc = 1 if args.batch else max(1, min(args.concurrent or ppg, ppg))
-    engines = []
-    for _ in range(nconc):
-        e = Engine(p, device=local_rank)
-        e.set_option(OPT_PROFILE, 1)
-        e.set_option(OPT_SCHEDULE, args.schedule)
-        if not mock and args.debug:
-            e.set_option(_lib.SGM_OPT_DEBUG, args.debug)
-        if not mock and args.prepass_rows:
-            e.set_option(_lib.SGM_OPT_PREPASS_ROWS, args.prepass_rows)
-        if not mock and args.sweep_rows:
-            e.set_option(_lib.SGM_OPT_SWEEP_ROWS, args.sweep_rows)
-        if not mock and args.chain_wgs:
-            e.set_option(_lib.SGM_OPT_CHAIN_WGS, args.chain_wgs)
-        engines.append(e)
+    def make_engine(sched, stream=None):
+        e = Engine(p, device=local_rank, stream=stream) if not mock else Engine(p, device=local_rank)
+        e.set_option(OPT["PROFILE"], 1)
+        e.set_option(OPT["SCHEDULE"], sched)
+        if not mock:
+            for name, val in (("DEBUG", args.debug), ("PREPASS_ROWS", args.prepass_rows), ("SWEEP_ROWS", args.sweep_rows),
+                              ("CHAIN_WGS", args.chain_wgs)):
+                if val:
+                    e.set_option(OPT[name], val)
+        return e
+
+    # batch entry: ONE engine (it keeps a group of internal engines, one per pair of the batch);
+    # otherwise `nconc` engines = HIP streams, pair i of a step on engine i % nconc
+    cstream = torch.cuda.Stream(dev) if (not mock and world > 1) else None   # the engine works on a torch stream (ordered against RCCL by events)
+    nconc = 1 if batch else max(1, min(args.concurrent or ppg, ppg))
+    engines = [make_engine(schedule, cstream.cuda_stream if (cstream is not None and k == 0) else None) for k in range(nconc)]
     eng = engines[0]
 
-    def run_local(lefts, rights, disps, dispfs, xyzs):
-        """enqueue every pair of this rank on its engine, then collect the HIP-event stage times"""
-        acc = []
+    def enqueue(lefts, rights, disps, dispfs, xyzs):
+        """enqueue every pair; returns the engines that have to be collected / synchronised"""
         n = len(lefts)
-        if args.batch:
+        if batch:
             ptrs = lambda ts: [t.data_ptr() for t in ts] if ts is not None else None
             eng.pipeline_batch_device(ptrs(lefts), ptrs(rights), H, W, W, Q if with_xyz else None, ptrs(disps),
                                       ptrs(dispfs) if with_xyz else None, ptrs(xyzs) if with_xyz else None)
-            st = eng.stage_times()       # (synchronises; the first pair's stages + the joint sweep launches)
-            return [st] * n
-        for i0 in range(0, n, nconc):
-            group = range(i0, min(i0 + nconc, n))
-            for i in group:  # enqueue on every stream first ...
-                engines[i % nconc].pipeline_device(
-                    lefts[i].data_ptr(), rights[i].data_ptr(), H, W, W, Q if with_xyz else None, disps[i].data_ptr(),
-                    dispfs[i].data_ptr() if with_xyz else None, xyzs[i].data_ptr() if with_xyz else None)
-            for i in group:  # ... then collect the stage times (synchronises that stream)
-                acc.append(engines[i % nconc].stage_times())
+            return [eng]
+        used = []
+        for i in range(n):
+            e = engines[i % nconc]
+            e.pipeline_device(lefts[i].data_ptr(), rights[i].data_ptr(), H, W, W, Q if with_xyz else None, disps[i].data_ptr(),
+                              dispfs[i].data_ptr() if with_xyz else None, xyzs[i].data_ptr() if with_xyz else None)
+            if e not in used:
+                used.append(e)
+        return used
+
+    def run_local(lefts, rights, disps, dispfs, xyzs):
+        """one step on this rank's resident pairs; returns one stage-time list per engine that took part (the batch
+        entry: the first pair's own stages + the joint sweep launches)"""
+        n = len(lefts)
+        if batch or nconc >= n:
+            return [e.stage_times() for e in enqueue(lefts, rights, disps, dispfs, xyzs)]   # (stage_times synchronises its stream)
+        acc = []
+        for i0 in range(0, n, nconc):   # an engine holds the stage events of its LAST compute only: collect per round
+            sl = slice(i0, min(i0 + nconc, n))
+            acc += [e.stage_times() for e in enqueue(lefts[sl], rights[sl], disps[sl], dispfs[sl] if with_xyz else None,
+                                                     xyzs[sl] if with_xyz else None)]
         return acc
-
-    stage_log = []
-
-    def ingest_compute(l, r):
-        """compute() of dist.run_sharded: this rank's shard [n, H, W] -> (disp[, xyz])"""
-        l, r = l.to(dev), r.to(dev)
-        n = l.shape[0]
-        disp = alloc((n, H, W), dtype=torch.int16, device=dev)
-        dispf = alloc((n, H, W), dtype=torch.float32, device=dev) if with_xyz else None
-        xyz = alloc((n, H, W, 3), dtype=torch.float32, device=dev) if with_xyz else None
-        sync()
-        stage_log.extend(run_local([l[i] for i in range(n)], [r[i] for i in range(n)], [disp[i] for i in range(n)],
-                                   [dispf[i] for i in range(n)] if with_xyz else None,
-                                   [xyz[i] for i in range(n)] if with_xyz else None))
-        if with_xyz:
-            return disp.to(comm_dev), xyz.to(comm_dev)
-        return disp.to(comm_dev)
-
-    def step_ingest(lefts0, rights0):
-        """one timed step of --ingest rank0: scatter u8 frames, compute, gather disparity (+ XYZ)"""
-        return sharding.run_sharded(ingest_compute, lefts0, rights0, src=0, device=comm_dev)
-
-    all_left = all_right = None
-    if args.ingest == "rank0" and rank == 0:
-        all_left = torch.stack(d_left).to(comm_dev)
-        all_right = torch.stack(d_right).to(comm_dev)
-
-    def step():
-        if args.ingest == "rank0":
-            step_ingest(all_left, all_right)
-            return []
-        return run_local(d_left, d_right, d_disp, d_dispf, d_xyz)
 
     def barrier():
         sync()
@@ -351,14 +369,55 @@ def main():
             dist.barrier()
         sync()
 
-    for _ in range(args.warmup):
-        step()
-    stage_log.clear()
+    # ---- rank-0 ingest: scatter / compute / gather as a pipeline (dist.IngestPipeline) ----
+    piped = batch and cstream is not None and not rehearse     # stream-ordered: nothing synchronises inside a step
+
+    def ingest_compute(l, r):
+        """compute() of the pipeline: this rank's shard [n, H, W] (on comm_dev) -> results on comm_dev; on the GPU box
+        nothing is synchronised here (the pipeline orders the engine's stream against the transfers with events)"""
+        with (torch.cuda.stream(cstream) if piped else _null()):
+            l, r = l.to(dev), r.to(dev)
+            n = l.shape[0]
+            disp = alloc((n, H, W), dtype=torch.int16, device=dev)
+            dispf = alloc((n, H, W), dtype=torch.float32, device=dev) if with_xyz else None
+            xyz = alloc((n, H, W, 3), dtype=torch.float32, device=dev) if with_xyz else None
+        if not piped:
+            sync()
+        used = enqueue([l[i] for i in range(n)], [r[i] for i in range(n)], [disp[i] for i in range(n)],
+                       [dispf[i] for i in range(n)] if with_xyz else None, [xyz[i] for i in range(n)] if with_xyz else None) if n else []
+        if not piped:
+            for e in used:
+                e.synchronize()
+        if with_xyz:
+            return disp.to(comm_dev), xyz.to(comm_dev)
+        return disp.to(comm_dev)
+
+    def ingest_steps(all_l, all_r, nsteps):
+        """`nsteps` batches through the pipeline; rank 0 gets the list of per-step results"""
+        pipe = sharding.IngestPipeline(ingest_compute, src=0, device=comm_dev, compute_stream=cstream if piped else None)
+        for _ in range(nsteps):
+            pipe.step(all_l, all_r)
+        return pipe.drain()
+
+    all_left = all_right = None
+    if args.ingest == "rank0" and rank == 0:
+        all_left = torch.stack(d_left).to(comm_dev)
+        all_right = torch.stack(d_right).to(comm_dev)
+
+    # ---- warm-up, timed region ----
+    if args.ingest == "rank0":
+        ingest_steps(all_left, all_right, args.warmup)
+    else:
+        for _ in range(args.warmup):
+            run_local(d_left, d_right, d_disp, d_dispf, d_xyz)
     barrier()
     t0 = time.perf_counter()
     stage_acc = []
-    for _ in range(args.steps):
-        stage_acc.extend(step())
+    if args.ingest == "rank0":
+        ingest_steps(all_left, all_right, args.steps)
+    else:
+        for _ in range(args.steps):
+            stage_acc.extend(run_local(d_left, d_right, d_disp, d_dispf, d_xyz))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -366,94 +425,84 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if args.ingest == "rank0":
-        stage_acc = list(stage_log)
-
-    # ---- the collective path on hardware, outside the timed region (default N > 1 runs) ----
-    ingest_check = None
-    if world > 1 and args.ingest == "resident":
-        t1 = time.perf_counter()
-        ls = torch.stack(d_left).to(comm_dev)
-        rs = torch.stack(d_right).to(comm_dev)
-        gl = sharding.gather_results(ls, ppg * world, dst=0)       # frames to rank 0 ...
-        gr = sharding.gather_results(rs, ppg * world, dst=0)
-        res = step_ingest(gl, gr)                                   # ... and through scatter / compute / gather
-        mine = torch.stack(d_disp).to(comm_dev)
-        ref = sharding.gather_results(mine, ppg * world, dst=0)
-        if rank == 0:
-            got = res[0] if isinstance(res, tuple) else res
-            ingest_check = {"ok": bool(torch.equal(got, ref)), "frames": ppg * world, "xyz": bool(with_xyz),
-                            "backend": "gloo" if rehearse else "nccl", "s": None}
-        barrier()
-        if rank == 0:
-            ingest_check["s"] = time.perf_counter() - t1
+        stage_acc = [eng.stage_times()]     # (the last batch this rank computed)
 
     # ---- per-stage HIP-event durations (this rank) ----
     stage_acc = [[t for t in st if t[0] != "_wall"] for st in stage_acc]
     names = [n for n, _, _ in stage_acc[0]]
-    ms = np.array([[m for _, m, _ in st] for st in stage_acc])  # [frames][stages]
+    stage_acc = [st for st in stage_acc if [n for n, _, _ in st] == names]
+    ms = np.array([[m for _, m, _ in st] for st in stage_acc])  # [collected engines][stages]
     mean_ms = ms.mean(axis=0)
+    launches = np.array([[n for _, _, n in st] for st in stage_acc]).mean(axis=0)
     if args.stages and rank == 0:
         for n, m in zip(names, mean_ms):
-            print(f"  {n:<14s} {m:9.4f} ms", file=sys.stderr)
-        print(f"  {'sum':<14s} {mean_ms.sum():9.4f} ms   wall/frame {dt / args.steps / ppg * 1e3:9.4f} ms", file=sys.stderr)
-
-    # ---- roofline of the dominant kernel ----
-    # Stages are grouped by the kernel that runs in them (both pre-pass stages are k_prepass3; the two
-    # sweeps are different template instantiations = different kernels, as in rocprofv3's kernel
-    # stats).  Dominant = the kernel with the largest total HIP-event time per frame, every stage a
-    # candidate.  `achieved` = bytes one launch moves through HBM / its average launch duration
-    # (HIP events: total stage time / launches): the PMC record of exactly these kernels when one is
-    # committed (profiles/pmc_traffic.json, stamped with the source hash), else the minimal-traffic
-    # model of the design -- a fraction of peak by construction.  The SURVEY 8(d)
-    # algorithmic model (unfused: 3 V per path scan) is kept as separate fields.
-    _, W1 = eng.geometry(W)
-    V = 2 * H * max(W1, 0) * D
-    R = min(11, max(4, -(-H // (200 if mode else 240))))   # rows per sweep band (sweep_rows_for in sgm_engine.hip)
-    launches = np.array([[n for _, _, n in st] for st in stage_acc]).mean(axis=0)
-    by_kernel = {}
-    for n, m, nl in zip(names, mean_ms, launches):
-        k = STAGE_KERNEL.get(n, n)
-        rec = by_kernel.setdefault(k, {"ms": 0.0, "launches": 0.0, "stages": []})
-        rec["ms"] += float(m)
-        rec["launches"] += float(max(nl, 1))
-        rec["stages"].append(n)
-    kdom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
-    dom_stages = by_kernel[kdom]["stages"]
-    k_ms = by_kernel[kdom]["ms"] / by_kernel[kdom]["launches"]     # average launch duration
-    alg_model = {"sweep_dn": 12 * V, "sweep_up": 12 * V, "sweep_up_wta": 12 * V, "path_W_wta": 3 * V, "path_W": 3 * V,
-                 "cost_pix": V // 2, "cost_box": V // 2, "cost_hsum": V // 2, "cost_vsum": V // 2}
-    alg_launch = sum(alg_model.get(n, 0) for n in dom_stages) / by_kernel[kdom]["launches"]
-    traffic, basis, pmc_stages = None, "model", {}
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            rec = json.load(open(pmc))
-            if rec.get("workload") == args.workload and rec.get("source_stamp") == source_stamp():
-                pmc_stages = rec.get("stages", {})
-                if all(n in pmc_stages for n in dom_stages):
-                    traffic = sum(pmc_stages[n]["traffic_bytes_per_launch"] for n in dom_stages) / by_kernel[kdom]["launches"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
-    moved = traffic
-    if moved is None:
-        per_stage = [min_traffic_model(n, V, R, H * W, mode) for n in dom_stages]
-        moved = (sum(per_stage) / by_kernel[kdom]["launches"]) if all(x is not None for x in per_stage) else None
-    else:
-        basis = "pmc"
-    achieved = (moved / (k_ms * 1e-3) / 1e9) if moved else None
-    # the same kernel where it has the GPU to itself (the downward pre-pass; the upward one shares it with the sweep)
-    alone = None
-    if "prepass_dn" in dom_stages and moved:
-        i = names.index("prepass_dn")
-        a_ms = float(mean_ms[i]) / max(1, int(launches[i]))
-        alone = {"stage": "prepass_dn", "avg_launch_ms": a_ms, "achieved": moved / (a_ms * 1e-3) / 1e9,
-                 "frac": moved / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    whole_traffic = sum(s.get("traffic_bytes_per_launch", 0) for s in pmc_stages.values()) or None
+            print(f"  {n:<14s} {m:9.4f} ms" + ("   (one launch for all pairs of the step)" if n in JOINT_STAGES and batch else ""), file=sys.stderr)
+        print(f"  {'sum':<14s} {mean_ms.sum():9.4f} ms   wall/pair {dt / args.steps / ppg * 1e3:9.4f} ms", file=sys.stderr)
 
     frames = args.steps * ppg * world
     mdisp = frames * H * W * D / dt / 1e6
-    alg_bytes = eng.algorithmic_bytes(H, W, with_xyz)
     step_s = dt / args.steps
+    pair_s = step_s / ppg
+
+    # ---- traffic accounting and the roofline of the dominant kernel ----
+    # Vocabulary: nothing above 1 is called a fraction of peak.
+    #   floor_bytes     least HBM bytes a pair costs in any schedule of this design (floor_bytes())
+    #   traffic_bytes   what a pair really moved: PMC record of exactly these kernels (profiles/pmc_traffic.json,
+    #                   2*FETCH_SIZE + WRITE_SIZE per the guide, stamped with the source hash), else null
+    #   roofline        dominant kernel = largest total HIP-event time per step; achieved = bytes one launch of it moves
+    #                   (PMC, else the schedule's traffic model) / its average launch duration (HIP events, measured here)
+    _, W1 = eng.geometry(W)
+    V = 2 * H * max(W1, 0) * D
+    HW = H * W
+    chained = schedule == 2 and D > 64
+    R = 12 if chained else min(11, max(4, -(-H // (200 if mode else 240))))   # rows per band (sweep_rows_for in sgm_engine.hip)
+    if args.sweep_rows:
+        R = args.sweep_rows
+    per_step = lambda n: 1 if (n in JOINT_STAGES and batch) else ppg   # how often a stage runs per step
+    # Time of a stage per step.  Joint launches (batch entry) have the GPU to themselves: their HIP-event time is wall time.
+    # The per-pair stages of a batch run side by side on one stream per pair -- their brackets overlap and stretch each
+    # other, so what they cost the step is the step time NOT spent in joint launches, split in proportion to their
+    # HIP-event times.  Without the batch entry: HIP-event time x runs per step, as before.
+    joint_ms = sum(float(m) for n, m in zip(names, mean_ms) if n in JOINT_STAGES and batch)
+    rest_ev = sum(float(m) for n, m in zip(names, mean_ms) if not (n in JOINT_STAGES and batch))
+    rest_wall = max(step_s * 1e3 - joint_ms, 0.0)
+
+    def stage_ms_per_step(n, m):
+        if batch and n not in JOINT_STAGES:
+            return rest_wall * float(m) / rest_ev if rest_ev > 0 else 0.0
+        return float(m) * per_step(n)
+
+    by_kernel = {}
+    for n, m, nl in zip(names, mean_ms, launches):
+        k = STAGE_KERNEL.get(n, n)
+        rec = by_kernel.setdefault(k, {"ms_per_step": 0.0, "launches_per_step": 0.0, "stages": []})
+        rec["ms_per_step"] += stage_ms_per_step(n, m)
+        rec["launches_per_step"] += float(max(nl, 1)) * per_step(n)
+        rec["stages"].append(n)
+    kdom = max(by_kernel, key=lambda k: by_kernel[k]["ms_per_step"])
+    dom_stages = by_kernel[kdom]["stages"]
+    k_ms = by_kernel[kdom]["ms_per_step"] / by_kernel[kdom]["launches_per_step"]     # average launch duration
+    pmc_stages, basis = {}, "model"
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc) and not mock:
+        try:
+            rec = json.load(open(pmc))
+            wrec = rec.get("workloads", {}).get(args.workload)
+            if wrec and rec.get("source_stamp") == source_stamp() and wrec.get("schedule") == schedule and wrec.get("batch") == bool(batch):
+                pmc_stages = wrec.get("stages", {})
+        except (OSError, ValueError, KeyError):
+            pmc_stages = {}
+    traffic_pair = sum(s["bytes_per_pair"] for s in pmc_stages.values()) if pmc_stages else None
+    if pmc_stages and all(n in pmc_stages for n in dom_stages):
+        moved_step = sum(pmc_stages[n]["bytes_per_pair"] for n in dom_stages) * ppg
+        basis = "pmc"
+    else:
+        per = [model_traffic(n, V, R, HW, mode, D) for n in dom_stages]
+        moved_step = sum(per) * ppg if all(x is not None for x in per) else None
+    moved = moved_step / by_kernel[kdom]["launches_per_step"] if moved_step else None
+    achieved = (moved / (k_ms * 1e-3) / 1e9) if moved else None
+    floor_b = floor_bytes(V, HW, mode, with_xyz)
+    alg_bytes = eng.algorithmic_bytes(H, W, with_xyz)
 
     out = {
         "metric": "Mdisparities/s",
@@ -471,41 +520,86 @@ def main():
                                " (BENCH_REHEARSE: ranks share GPUs, numbers meaningless)" if rehearse else ""),
         "config": {"workload": f"{args.workload}: {desc}", "height": H, "width": W, "numDisparities": D,
                    "blockSize": bs, "mode": "MODE_HH" if mode else "MODE_SGBM", "pairs_per_gpu_per_step": ppg,
-                   "global_pairs_per_step": ppg * world, "streams_per_gpu": nconc, "batch_entry": bool(args.batch),
-                   "schedule": ("one kernel per direction", "fused sweeps", "chained sweeps")[args.schedule],
+                   "global_pairs_per_step": ppg * world, "streams_per_gpu": nconc, "batch_entry": bool(batch),
+                   "schedule": ("one kernel per direction", "fused sweeps behind a boundary pre-pass (latency mode)",
+                                "chained sweeps, no pre-pass (throughput mode)")[schedule],
                    **({"debug_mask": args.debug} if args.debug else {}),
                    "world_size": dist.get_world_size() if world > 1 else 1,
                    "frames_per_rank": [b - a for a, b in (sharding.shard_range(ppg * world, r, world) for r in range(world))],
                    "ingest": args.ingest,
                    "parallelism": (f"frame-sharded x{world}, rank 0 scatters frames / gathers results over "
-                                   f"{'gloo' if rehearse else 'RCCL'} inside the step" if args.ingest == "rank0"
+                                   f"{'gloo' if rehearse else 'RCCL'} inside the step (pipelined)" if args.ingest == "rank0"
                                    else f"frame-sharded x{world}, no data-path collective")},
         "pairs_per_s": frames / dt,
-        "algorithmic_GBps_whole_step": alg_bytes * ppg * world / step_s / 1e9,
-        "frac_whole_step": alg_bytes * ppg * world / step_s / 1e9 / HBM_PEAK_GBS / world,
-        "traffic_GBps_whole_step": (whole_traffic * ppg / step_s / 1e9) if whole_traffic else None,
-        "traffic_frac_whole_step": (whole_traffic * ppg / step_s / 1e9 / HBM_PEAK_GBS) if whole_traffic else None,
+        "ms_per_pair": pair_s * 1e3 / world,
+        # bytes per pair: the design's floor, what the PMC counters saw, and the SURVEY 8(d) model of an UNFUSED
+        # implementation (3 V per path scan) -- the last one is context only, the fused design moves fewer bytes than it
+        "floor_bytes": floor_b,
+        "traffic_bytes": traffic_pair,
+        "traffic_over_floor": (traffic_pair / floor_b) if traffic_pair else None,
+        "time_over_floor_at_6.29TBps": pair_s / (floor_b / (HBM_COPY_GBS * 1e9)),
+        "traffic_GBps_per_gpu": (traffic_pair / pair_s / 1e9) if traffic_pair else None,
+        "traffic_frac_of_peak_per_gpu": (traffic_pair / pair_s / 1e9 / HBM_PEAK_GBS) if traffic_pair else None,
+        "unfused_model_bytes": alg_bytes,
+        "unfused_model_GBps_per_gpu": alg_bytes / pair_s / 1e9,
         "roofline": {"bound": "hbm", "kernel": kdom, "stages": dom_stages,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                     "traffic": traffic, "basis": basis, "bytes_per_launch": moved, "avg_launch_ms": k_ms,
-                     "launches_per_step": by_kernel[kdom]["launches"] * ppg, "kernel_ms_per_frame": by_kernel[kdom]["ms"],
-                     "algorithmic_bytes_per_launch": alg_launch,
-                     "algorithmic_GBps": alg_launch / (k_ms * 1e-3) / 1e9,
-                     "alone": alone,
-                     "note": "dominant = kernel with the largest total HIP-event time per frame (all stages); achieved = "
-                             "bytes one launch moves (PMC 2*FETCH_SIZE+WRITE_SIZE of these kernels when basis=pmc, else "
-                             "the design's minimal-traffic model) / average launch duration; the upward pre-pass shares "
-                             "the GPU with the downward sweep (auxiliary stream), which lengthens both; algorithmic_* = "
-                             "SURVEY 8(d) unfused model (a fused sweep = 4 path scans = 12 V; the pre-pass has no "
-                             "counterpart = 0)"},
+                     "traffic": moved if basis == "pmc" else None, "basis": basis, "bytes_per_launch": moved, "avg_launch_ms": k_ms,
+                     "launches_per_step": by_kernel[kdom]["launches_per_step"], "kernel_ms_per_step": by_kernel[kdom]["ms_per_step"],
+                     "pairs_per_launch": ppg if (batch and all(n in JOINT_STAGES for n in dom_stages)) else 1,
+                     "note": "dominant = kernel with the largest total HIP-event time per step; achieved = HBM bytes one launch of it "
+                             "moves (basis pmc: 2*FETCH_SIZE + WRITE_SIZE of exactly these kernels, profiles/pmc_traffic.json; basis "
+                             "model: the schedule's traffic model, DESIGN.md 4.2) / its average launch duration (HIP events around "
+                             "the launch, on its stream, measured in this run)"},
         "stage_ms": {n: float(m) for n, m in zip(names, mean_ms)},
     }
-    if ingest_check is not None:
-        out["rccl_ingest_check"] = ingest_check
+
+    # ---- N > 1, resident: the rank-0 ingest path on hardware, timed over the same number of steps ----
+    # (scatter / compute / gather pipeline over RCCL; never run on real multi-GPU hardware before the driver's scaling
+    #  run -- so a watchdog prints the finished headline line if it stalls, and any exception is reported, not raised)
+    if world > 1 and args.ingest == "resident" and not args.no_ingest_leg:
+        state = {"done": False}
+
+        def watchdog():
+            t_end = time.time() + float(os.environ.get("BENCH_INGEST_TIMEOUT", "240"))
+            while time.time() < t_end:
+                if state["done"]:
+                    return
+                time.sleep(0.5)
+            if rank == 0:
+                out["ingest_rank0"] = {"ok": False, "error": "timed out (watchdog): the scatter / gather leg did not finish"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            ls = torch.stack(d_left).to(comm_dev)
+            rs = torch.stack(d_right).to(comm_dev)
+            gl = sharding.gather_results(ls, ppg * world, dst=0)       # frames to rank 0 ...
+            gr = sharding.gather_results(rs, ppg * world, dst=0)
+            ingest_steps(gl, gr, 1)                                     # (buffers, communicators)
+            barrier()
+            t1 = time.perf_counter()
+            res = ingest_steps(gl, gr, args.steps)                      # ... and through the pipeline
+            barrier()
+            idt = time.perf_counter() - t1
+            mine = torch.stack(d_disp).to(comm_dev)
+            ref = sharding.gather_results(mine, ppg * world, dst=0)
+            if rank == 0:
+                got = res[-1][0] if isinstance(res[-1], tuple) else res[-1]
+                out["ingest_rank0"] = {"ok": bool(torch.equal(got, ref)), "frames_per_step": ppg * world, "xyz": bool(with_xyz),
+                                       "backend": "gloo" if rehearse else "nccl", "steps": args.steps,
+                                       "ms_per_step": idt / args.steps * 1e3, "pairs_per_s": args.steps * ppg * world / idt,
+                                       "note": "rank 0 owns every frame: scatter of step k + 2 and gather of step k beside the compute of "
+                                               "step k + 1 (dist.IngestPipeline), every scatter / gather one batch of point-to-point transfers"}
+        except Exception as ex:  # noqa: BLE001 -- the measurement above must survive whatever happens here
+            if rank == 0:
+                out["ingest_rank0"] = {"ok": False, "error": f"{type(ex).__name__}: {ex}"[:500]}
+        state["done"] = True
 
     # ---- CPU baseline: the oracle (a scalar port, one thread per frame like upstream), bounded
-    # sample, rank 0 at N = 1; plus the frame-parallel all-cores rate (one frame per core) ----
+    # sample, rank 0 at N = 1; plus the frame-parallel rate on every usable core (one frame per core) ----
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not mock:
         from concurrent.futures import ThreadPoolExecutor
 
@@ -528,9 +622,11 @@ def main():
                       f"(upstream MODE_SGBM / MODE_HH are single-threaded)",
         }
         out["speedup_vs_cpu_baseline"] = mdisp / out["cpu_baseline"]["value"]
-        # frame-parallel: `usable` threads, each one frame-sample of its own (ctypes releases the GIL)
-        nthreads = max(1, min(usable, 64))
-        prow = max(32, min(rows, int(rows * 1.0 / max(cdt, 1e-3))))   # about 1 s per thread alone (several when all contend for memory)
+        # frame-parallel: one thread per usable core, each one frame-sample of its own (ctypes releases the GIL)
+        nthreads = max(1, min(usable, 256))
+        # about 1 s per thread alone on up to 64 threads, a quarter of that beyond (all threads contend for memory: the
+        # whole leg stays near 15 s)
+        prow = max(32, min(rows, int(rows * (1.0 if nthreads <= 64 else 0.25) / max(cdt, 1e-3))))
         pl, pr = pairs[0][0][:prow], pairs[0][1][:prow]
 
         def one(_):
@@ -543,23 +639,44 @@ def main():
         with ThreadPoolExecutor(nthreads) as ex:
             list(ex.map(one, range(nthreads)))
         pdt = time.perf_counter() - t0
-        out["cpu_baseline"]["all_cores"] = {
+        out["cpu_baseline"]["all_threads"] = {
             "value": nthreads * prow * W * D / pdt / 1e6, "unit": "Mdisparities/s", "cores": nthreads,
-            "sample": f"{nthreads} threads, each rows 0..{prow - 1} of the pair (one frame per core, the batch "
-                      f"configs' CPU counterpart), {pdt:.1f} s wall",
+            "sample": f"{nthreads} threads (every usable core), each rows 0..{prow - 1} of the pair (one frame per core, the "
+                      f"batch configs' CPU counterpart), {pdt:.1f} s wall",
         }
-        out["speedup_vs_cpu_all_cores"] = mdisp / out["cpu_baseline"]["all_cores"]["value"]
+        out["speedup_vs_cpu_all_threads"] = mdisp / out["cpu_baseline"]["all_threads"]["value"]
+
+    # ---- the same configuration, one pair at a time in latency mode (pre-pass schedule), N = 1 only ----
+    if world == 1 and rank == 0 and not mock and not args.no_latency_mode and (ppg > 1 or schedule != 1):
+        e1 = make_engine(1)
+        lat = []
+        for it in range(5):
+            sync()
+            t0 = time.perf_counter()
+            e1.pipeline_device(d_left[0].data_ptr(), d_right[0].data_ptr(), H, W, W, Q if with_xyz else None, d_disp[0].data_ptr(),
+                               d_dispf[0].data_ptr() if with_xyz else None, d_xyz[0].data_ptr() if with_xyz else None)
+            e1.synchronize()
+            lat.append(time.perf_counter() - t0)
+        out["latency_mode"] = {"ms_per_pair": float(np.median(lat[1:]) * 1e3), "pairs_per_s": 1.0 / float(np.median(lat[1:])),
+                               "schedule": "fused sweeps behind a boundary pre-pass", "pairs_in_flight": 1,
+                               "note": "one pair per call through sgm_pipeline_device, host-timed call to completion (HIP-event profiling on)"}
+        del e1
+
     if args.verify and world == 1 and rank == 0 and not mock and args.ingest == "resident":
         from oracle import oracle as O  # the checker (test infrastructure)
+        run_local(d_left, d_right, d_disp, d_dispf, d_xyz)      # (the latency-mode leg above reused the first output buffers)
         t0 = time.perf_counter()
-        full = O.sgbm_compute(pairs[0][0], pairs[0][1], taps=False, **p)
-        got = d_disp[0].cpu().numpy()
-        nbad = int((got != full).sum())
-        out["verify"] = {"full_frame_mismatches": nbad, "pixels": int(got.size),
+        nbad, nver = 0, 0
+        for i in range(min(ppg, nuniq)):
+            full = O.sgbm_compute(pairs[i][0], pairs[i][1], taps=False, **p)
+            got = d_disp[i].cpu().numpy()
+            nbad += int((got != full).sum())
+            nver += 1
+        out["verify"] = {"full_frame_mismatches": nbad, "pairs_verified": nver, "pixels": int(H * W * nver),
                          "valid_fraction": float((got >= 0).mean()), "oracle_s": time.perf_counter() - t0}
         if with_xyz:
             ref = O.reproject(O.disp_to_float(full), Q)
-            x = d_xyz[0].cpu().numpy()
+            x = d_xyz[min(ppg, nuniq) - 1].cpu().numpy()
             fin = np.isfinite(ref)
             out["verify"]["xyz_finite_mask_equal"] = bool(np.array_equal(np.isfinite(x), fin))
             out["verify"]["xyz_max_rel_err"] = float(np.max(np.abs(x[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-30))) if fin.any() else 0.0
@@ -568,6 +685,14 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 if __name__ == "__main__":

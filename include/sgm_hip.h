@@ -91,22 +91,8 @@ typedef enum {
     SGM_OPT_SWEEP_ROWS = 3,  /* rows per band of the fused sweep; 0 = automatic                  */
     SGM_OPT_CHAIN_WGS = 6,   /* schedule 2: workgroups (bands in flight) per sweep launch; 0 = automatic       */
     SGM_OPT_PREPASS_ROWS = 5, /* rows per chunk (= launch) of the boundary pre-pass; 0 = automatic (about 135, a multiple of 8) */
-    SGM_OPT_DEBUG = 4        /* A/B switches for measurements, a bit mask.  Results stay correct except
-                              * for bit 64.   2: winner-take-all fused into the last path kernel
-                              * everywhere;  4: no lane groups for D <= 64;  8: narrow vertical box
-                              * sum;  16: boundary pre-pass as three k_path launches;  32: no overlap of
-                              * the upward pre-pass with the downward sweep;  64: the sweep's loader wave
-                              * skips its HBM loads (timing only, results WRONG);  128: fork the upward
-                              * pre-pass right after the cost stage;  256: int16 cost pipeline (k_hsum +
-                              * k_vsum_ring) instead of the byte one;  512: boundary pre-pass in one chunk
-                              * with the plain line-per-block layout (no XCD grouping);  2048: winner-take-all
-                              * always as its own pass;  4096: D <= 64 with the three-role grouped pre-pass and
-                              * the four-direction row kernel (round 1) instead of per-role pre-pass + element-wise
-                              * vertical kernel + in-row kernel;  8192: that small-D schedule for D <= 32 only;
-                              * 16384: D = 256, the upward pre-pass (the one beside the sweep) with prefetch
-                              * blocks of 2 rows (70 registers instead of 106);  65536: MODE_SGBM with D <= 128: the fifth
-                              * path after the sweep, accumulating into S, instead of beside it into a volume of its
-                              * own that the winner-take-all adds */
+    /* 4 = SGM_OPT_DEBUG: A/B switches for measurements -- not part of this interface (csrc/sgm_debug.h) */
+    SGM_OPT_RESERVED_4 = 4
 } sgm_option;
 
 #define SGM_MAX_STAGES 32

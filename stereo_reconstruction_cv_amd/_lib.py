@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("SGM_HIP_LIB") or os.path.join(_HERE, "csrc", "libsgm_
 
 SGM_OK = 0
 SGM_TAP_COST, SGM_TAP_AGGR, SGM_TAP_DISP_RAW, SGM_TAP_DISP_MEDIAN = 0, 1, 2, 3
-SGM_OPT_KEEP_AGGR, SGM_OPT_PROFILE, SGM_OPT_SCHEDULE, SGM_OPT_SWEEP_ROWS, SGM_OPT_DEBUG, SGM_OPT_PREPASS_ROWS, SGM_OPT_CHAIN_WGS = 0, 1, 2, 3, 4, 5, 6
+SGM_OPT_KEEP_AGGR, SGM_OPT_PROFILE, SGM_OPT_SCHEDULE, SGM_OPT_SWEEP_ROWS, SGM_OPT_PREPASS_ROWS, SGM_OPT_CHAIN_WGS = 0, 1, 2, 3, 5, 6
+SGM_OPT_DEBUG = 4    # csrc/sgm_debug.h: A/B switches for tools/ and tests/, not part of the public interface
 SGM_MAX_STAGES = 32
 
 # every symbol include/sgm_hip.h declares (checked by tests/test_abi.py)

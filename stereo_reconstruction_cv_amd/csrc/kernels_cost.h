@@ -414,8 +414,7 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
 // register rings.  2.5 bytes read per output byte pair instead of 7: the first version (one column
 // per wave) was bound by L2 traffic.
 template <int R, int NP>
-__global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restrict__ pix, int16_t *__restrict__ C, int RB,
-                                                int band0 /* the launch covers bands band0 .. band0 + gridDim.y - 1 */)
+__global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restrict__ pix, int16_t *__restrict__ C, int RB)
 {
     constexpr int RS = R <= 1 ? 4 : (R <= 3 ? 8 : 16);  // pow2 >= 2R+2
     constexpr int XC = 4, NT = 2 * R + XC;
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restric
     const int W1 = g.W1, D = g.D, H = g.H;
     if (x0 >= W1) return;
     const bool active = 2 * NP * lane < D;
-    const int y0 = (band0 + blockIdx.y) * RB, y1 = min(y0 + RB, H);
+    const int y0 = (int)blockIdx.y * RB, y1 = min(y0 + RB, H);
     const int row_bytes = W1 * D;
     // (the host takes this pipeline only while H * row_bytes < 2 GiB; plain 32-bit scalar arithmetic -- a
     // min<int64_t>() here went through v_min_f64 and dragged the descriptor into VGPRs: see uniform_rsrc)
@@ -637,15 +636,14 @@ __global__ __launch_bounds__(256) void k_vsum(const int16_t *__restrict__ hs, in
 // by RS).  Instantiated for the common block sizes; other sizes use k_vsum.
 template <int SH2_, int NW /* dwords per thread: 2 or 4 */>
 __global__ __launch_bounds__(256) void k_vsum_ring(const int16_t *__restrict__ hs, int16_t *__restrict__ C,
-                                                   int H, int64_t rowsz, int RB /* multiple of RS */, int band0,
-                                                   uint32_t *hr)
+                                                   int H, int64_t rowsz, int RB /* multiple of RS */, uint32_t *hr)
 {
     constexpr int RS = SH2_ <= 1 ? 4 : (SH2_ <= 3 ? 8 : (SH2_ <= 7 ? 16 : 32));  // pow2 >= 2*SH2+2
     typedef Pack<NW> V;
     const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (2 * NW);  // 2*NW int16 per thread
     uint32_t hmax = 0;  // headroom record (packed running maximum)
     if (e < rowsz) {
-    const int y0 = (band0 + blockIdx.y) * RB, y1 = min(y0 + RB, H);
+    const int y0 = (int)blockIdx.y * RB, y1 = min(y0 + RB, H);
     V ring[RS];
     V acc;
     acc.fill(0);

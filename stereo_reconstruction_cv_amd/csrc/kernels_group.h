@@ -130,14 +130,14 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
     headroom_commit_pk(g.hr, 1, active ? hm : 0u);
 }
 
-// The four directions of a pass (in-row + the three from the previous row) for D <= 64, 64/GW rows
-// per wave, NO hand-off between rows: with band height 1 the boundary pre-pass has already left the
-// normalised state of every row's three vertical predecessors in HBM (bnd[row][x][role][D], as the
-// fused sweep's loader reads it), so a row needs nothing from its neighbours at run time -- no LDS
-// ring, no lockstep, no barrier.  For small D that trade is cheap (the state of a row is 3*W1*D*2
-// bytes) and removes what bounds k_sweep there: its instruction stream per pixel does not shrink
-// with D and three waves share the busiest SIMD.  Only the in-row path needs its minimum (the other
-// three are not propagated from here); S = sat(sum) as everywhere.  MODE: PATH_FIRST / PATH_ACCUM.
+// Small-D schedule (D <= 64), NO hand-off between rows: with band height 1 the boundary pre-pass leaves the
+// normalised state of every row's three vertical predecessors in HBM, so a row needs nothing from its
+// neighbours at run time -- no LDS ring, no lockstep, no barrier.  For small D that trade is cheap (the
+// state of a row is 3*W1*D*2 bytes) and removes what bounds k_sweep there: its instruction stream per
+// pixel does not shrink with D and three waves share the busiest SIMD.  The three directions from the
+// previous row are then element-wise (k_vert3_g), only the in-row path is a recurrence (k_rows_g).
+// (Round 1 walked all four directions along the rows in one kernel, k_rows4_g; round 2 measured the split
+// form ahead -- 4K D=16: 1.25 + 0.89 -> 0.39 + 0.56 ms -- and round 3 removed the old kernel.)
 // Per-row state of the small-D schedule (band height 1): one record of 3 * W1 * D int16 per row.  The grouped
 // pre-pass writes it ROLE-MAJOR, [row][role][x][D]: a wave (one role, 64 / GW adjacent columns) then stores
 // 64 / GW * D * 2 contiguous bytes -- whole lines; in the band layout [row][x][role][D] of the large-D
@@ -149,122 +149,20 @@ __device__ __forceinline__ int bnd_px_off(int role_major, int W1, int x, int rol
     return role_major ? role * W1 + x : x * 3 + role;
 }
 
-template <int GW, int MODE>
-__global__ __launch_bounds__(64) void k_rows4_g(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
-                                                int16_t *__restrict__ S, const int16_t *__restrict__ bnd,
-                                                int role_major /* layout of bnd: see bnd_px_off */)
-{
-    constexpr int G = 64 / GW, NP = 1, PB = 8;
-    constexpr int OOB = (int)0xfffffff0u;  // beyond every descriptor used here (they span < 4 GiB)
-    const int lane = threadIdx.x, gi = lane / GW, li = lane % GW;
-    const int W1 = g.W1, D = g.D, H = g.H;
-    const int j = blockIdx.x * G + gi;  // row index in sweep order
-    const int y = ydir > 0 ? j : H - 1 - j;
-    const bool active = 2 * li < D && j < H;
-    const bool has_prev = j > 0;
-    GroupEdge ge;
-    ge.first = li == 0;
-    ge.last = li == GW - 1;
-    const int row_bytes = W1 * D * 2;
-    const uint32_t vol = (uint32_t)H * (uint32_t)row_bytes;
-    const __amdgpu_buffer_rsrc_t Cv = __builtin_amdgcn_make_buffer_rsrc((void *)C, 0, (int)vol, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Sv = __builtin_amdgcn_make_buffer_rsrc((void *)S, 0, (int)vol, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Bv = __builtin_amdgcn_make_buffer_rsrc((void *)bnd, 0, (int)(3u * vol), 0x00020000);
-    const int voff = active ? y * row_bytes + li * 4 : OOB;
-    // boundary record of this row: [j][x][3][D]; rows without a predecessor read "nothing" = the zero state
-    const int bvoff = (active && has_prev) ? (int)((uint32_t)j * 3u * (uint32_t)row_bytes) + li * 4 : OOB;
-    const int pxb = D * 2;
-    const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
-    const uint32_t init = active ? 0u : SGM_SENT;
-    constexpr bool READS_S = MODE == PATH_ACCUM;
-    const int x0 = xdir > 0 ? 0 : W1 - 1;
-
-    Pack<NP> L0;  // normalised state of the in-row path
-    L0.fill(init);
-    ShiftRegs sr0, srA, srB, srC;
-    uint32_t hm = 0;  // headroom record, in-row direction
-    struct Px {
-        Pack<NP> c, s, qa, qb, qc;
-    };
-    Px pA[PB], pB[PB];
-    auto load_t = [&](auto full_c, Px *pb, int k0) {
-        constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-        for (int u = 0; u < PB; u++)
-            if (FULL || k0 + u < W1) {
-                const int k = k0 + u, x = x0 + k * xdir;
-                const int xa = min(max(x - xdir, 0), W1 - 1), xc = min(max(x + xdir, 0), W1 - 1);
-                buf_load<NP>(pb[u].c, Cv, voff, x * pxb);
-                if (READS_S) buf_load<NP>(pb[u].s, Sv, voff, x * pxb);
-                buf_load<NP>(pb[u].qa, Bv, bvoff, bnd_px_off(role_major, W1, xa, 0) * pxb);
-                buf_load<NP>(pb[u].qb, Bv, bvoff, bnd_px_off(role_major, W1, x, 1) * pxb);
-                buf_load<NP>(pb[u].qc, Bv, bvoff, bnd_px_off(role_major, W1, xc, 2) * pxb);
-            }
-    };
-    auto pixel = [&](const Px &p, int k) {
-        // out-of-image predecessors (k-1 < 0, k+1 >= W1) and idle lanes: start state / sentinel
-        Pack<NP> QA = p.qa, QB = p.qb, QC = p.qc;
-        if (k == 0) QA.fill(0u);
-        if (k == W1 - 1) QC.fill(0u);
-        if (!active) {
-            QA.fill(SGM_SENT);
-            QB.fill(SGM_SENT);
-            QC.fill(SGM_SENT);
-        }
-        Pack<NP> N0, NA, NB, NC, Ln;
-        uint32_t r0, rA, rB, rC;
-        path_elem<NP, true, GW>(p.c, L0, P1s, P2s, active, N0, r0, sr0, ge);
-        path_elem<NP, true, GW>(p.c, QA, P1s, P2s, active, NA, rA, srA, ge);
-        path_elem<NP, true, GW>(p.c, QB, P1s, P2s, active, NB, rB, srB, ge);
-        path_elem<NP, true, GW>(p.c, QC, P1s, P2s, active, NC, rC, srC, ge);
-        const uint32_t m0s = group_min_splat<GW>(r0);
-        hm = max(hm, m0s & 0xffffu);  // (the three other directions are recorded by k_prepass3_g)
-        path_normalise_splat<NP, true>(N0, m0s, active, Ln);
-        L0 = Ln;
-        Pack<NP> Sn;
-        uint32_t v = pk_adds_s(pk_adds_s(N0.r[0], NA.r[0]), pk_adds_s(NB.r[0], NC.r[0]));
-        if (READS_S) v = pk_adds_s(v, p.s.r[0]);
-        Sn.r[0] = v;
-        buf_store<NP>(Sn, Sv, voff, (x0 + k * xdir) * pxb);
-    };
-    auto compute_t = [&](auto full_c, Px *pb, int k0) {
-        constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-        for (int u = 0; u < PB; u++)
-            if (FULL || k0 + u < W1) pixel(pb[u], k0 + u);
-    };
-    const std::true_type full{};
-    const std::false_type part{};
-    int k0 = 0;
-    load_t(part, pA, 0);
-    for (; k0 + 3 * PB <= W1; k0 += 2 * PB) {  // straight-line steady state: loads stay in flight
-        load_t(full, pB, k0 + PB);
-        compute_t(full, pA, k0);
-        load_t(full, pA, k0 + 2 * PB);
-        compute_t(full, pB, k0 + PB);
-    }
-    for (; k0 < W1; k0 += 2 * PB) {
-        load_t(part, pB, k0 + PB);
-        compute_t(part, pA, k0);
-        load_t(part, pA, k0 + 2 * PB);
-        compute_t(part, pB, k0 + PB);
-    }
-    headroom_commit_pk(g.hr, 1, active ? hm : 0u);
-}
-
-// Boundary pre-pass for k_rows4_g (band height 1: the state after EVERY row is stored), 64/GW path
+// Boundary pre-pass of the small-D schedule (band height 1: the state after EVERY row is stored), 64/GW path
 // lines per wave.  Same walk as k_prepass3 -- a wave follows its lines down the image, three roles
 // each (rx = +xdir, 0, -xdir), diagonals wrap around the side border with a state reset -- but every
 // lane group has its own line, so columns, wraps and addresses are per-lane values handled without
 // branches; C rows are prefetched PF rows ahead through a statically indexed register ring.
-// SPLIT: one role per wave (role = blockIdx.y, grid.y = 3): three times the waves, a third of the work
-// each -- frames of small D have so few lines per SIMD that a wave's instruction latency bounds them.
-template <int GW, bool SPLIT>
+// One role per wave (role = blockIdx.y, grid.y = 3): frames of small D have so few lines per SIMD that a wave's
+// instruction latency bounds them (round 2 measured the three roles fused in one wave: 4K D=16 0.67-0.88 against
+// 0.39 ms; that form is gone).
+template <int GW>
 __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
                                                    int16_t *__restrict__ bnd)
 {
     constexpr int G = 64 / GW, NP = 1, PF = 8;
-    constexpr int NR = SPLIT ? 1 : 3;  // roles handled by this wave
+    constexpr int NR = 1;  // roles handled by this wave
     constexpr int OOB = (int)0xfffffff0u;
     const int lane = threadIdx.x, gi = lane / GW, li = lane % GW;
     const int W1 = g.W1, D = g.D, H = g.H;
@@ -279,7 +177,7 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
     const __amdgpu_buffer_rsrc_t Bv = __builtin_amdgcn_make_buffer_rsrc((void *)bnd, 0, (int)(3u * vol), 0x00020000);
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);
     const uint32_t init = active ? 0u : SGM_SENT;
-    const int role0 = SPLIT ? (int)blockIdx.y : 0;  // first (only) role of this wave
+    const int role0 = (int)blockIdx.y;  // the role of this wave
     int rx[NR];
 #pragma unroll
     for (int d = 0; d < NR; d++) rx[d] = (role0 + d) == 0 ? xdir : ((role0 + d) == 1 ? 0 : -xdir);
@@ -314,19 +212,9 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
         uint32_t r[NR];
 #pragma unroll
         for (int d = 0; d < NR; d++) path_elem<NP, true, GW>(cv[u][d], L[d], P1s, P2s, active, N[d], r[d], sr[d], ge);
-        if constexpr (SPLIT) {
-            const uint32_t m0s = group_min_splat<GW>(r[0]);
-            if (s < H) hm = max(hm, m0s & 0xffffu);
-            path_normalise_splat<NP, true>(N[0], m0s, active, L[0]);
-        } else {
-            uint32_t mm[2] = {pk_min_s(pack_lo(r[0], r[1]), pack_hi(r[0], r[1])), r[2]};
-            group_min_pk_n<GW, 2>(mm);
-            const uint32_t m2 = min(mm[1] & 0xffffu, mm[1] >> 16);
-            if (s < H) hm = max(hm, max(max(mm[0] & 0xffffu, mm[0] >> 16), m2));  // headroom record of the three directions
-            path_normalise<NP, true>(N[0], mm[0] & 0xffffu, active, L[0]);
-            path_normalise<NP, true>(N[1], mm[0] >> 16, active, L[1]);
-            path_normalise<NP, true>(N[2], m2, active, L[2]);
-        }
+        const uint32_t m0s = group_min_splat<GW>(r[0]);
+        if (s < H) hm = max(hm, m0s & 0xffffu);
+        path_normalise_splat<NP, true>(N[0], m0s, active, L[0]);
         // the state the row s + 1 will read: bnd[s + 1][role][column][D] (role-major: bnd_px_off)
 #pragma unroll
         for (int d = 0; d < NR; d++) {
@@ -353,7 +241,7 @@ __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, c
 // no recurrence here at all -- N_r(p, d) = C(p, d) + min(Q_r(d), Q_r(d +- 1) + P1, P2) is element-wise --
 // so the kernel is a plain streaming pass over all pixels (one lane group per pixel) instead of a walk
 // along the rows: S = sat(N_A + N_B + N_C [+ S]).  The in-row direction then runs as k_rows_g (ACCUM).
-// Same arithmetic as k_rows4_g without its in-row path.  MODE: PATH_FIRST / PATH_ACCUM.
+// MODE: PATH_FIRST / PATH_ACCUM.
 template <int GW, int MODE>
 __global__ __launch_bounds__(256) void k_vert3_g(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
                                                  int16_t *__restrict__ S, const int16_t *__restrict__ bnd,

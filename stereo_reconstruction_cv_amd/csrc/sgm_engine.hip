@@ -4,6 +4,7 @@
 // Mirrors the reference's call shape (cv2.StereoSGBM_create -> .compute -> reprojectImageTo3D,
 // /root/reference/main.ipynb:655-670, 697); see the header for the per-entry-point mapping.
 #include "../../include/sgm_hip.h"
+#include "sgm_debug.h"
 
 #include <hip/hip_runtime.h>
 
@@ -12,6 +13,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -550,14 +552,14 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         const int nvb = (H + RB - 1) / RB;
         const int16_t *hsp = (const int16_t *)HS;
         int16_t *cp = (int16_t *)e->cost.p;
-        auto launch_vsum = [&](int band0, int nb) {
+        auto launch_vsum = [&](int nb) {
             const bool wide = !(e->debug & 8);  // 8 int16 per thread (debug 8: 4, for A/B timing)
             const int per_thread = wide ? 8 : 4;
             dim3 block(256), gridr((unsigned)((g.rowsz / per_thread + 255) / 256), nb);
 #define SGM_VSUM(SH2_)                                                                                             \
     case SH2_:                                                                                                     \
-        if (wide) hipLaunchKernelGGL((k_vsum_ring<SH2_, 4>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, band0, g.hr); \
-        else hipLaunchKernelGGL((k_vsum_ring<SH2_, 2>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, band0, g.hr); \
+        if (wide) hipLaunchKernelGGL((k_vsum_ring<SH2_, 4>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, g.hr); \
+        else hipLaunchKernelGGL((k_vsum_ring<SH2_, 2>), gridr, block, 0, st, hsp, cp, H, g.rowsz, RB, g.hr); \
         break;
             switch (g.SH2) {  // ring variant: each hsum row is read once
                 SGM_VSUM(1)
@@ -575,7 +577,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // both kernels) the int16 pipeline is faster.  debug 256: the int16 pipeline always.
         const bool byte_cost = !(e->debug & 256) && g.D > 64 && g.SW2 >= 1 && g.SW2 <= 5 && 2 * g.ftzero + 63 <= 255 &&
                                (int64_t)H * g.rowsz < (int64_t)0x7ff00000;
-        // per-pixel cost of rows [y_lo, y_hi) / block cost of the bands [band_lo, band_lo + nb) of RB rows, on stream `on`
+        // per-pixel cost of rows [y_lo, y_hi) / block cost of the nb bands of RB rows, on stream `on`
         auto launch_pix = [&](int y_lo, int y_hi, hipStream_t on) {
             const int nj = XL + 2;
             const int lrec_b = ((nj * 8) + 15) & ~15;
@@ -587,15 +589,15 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             else if (g.NP == 2) hipLaunchKernelGGL(k_pix<2>, grid, block, lds, on, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l, y_lo);
             else hipLaunchKernelGGL(k_pix<4>, grid, block, lds, on, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l, y_lo);
         };
-        auto launch_box = [&](int band_lo, int nb, hipStream_t on) {
+        auto launch_box = [&](int nb, hipStream_t on) {
             dim3 grid((g.W1 + 15) / 16, nb), block(256);  // 4 waves x 4 columns per workgroup
             const uint8_t *px = (const uint8_t *)HS;
             int16_t *cp2 = (int16_t *)e->cost.p;
 #define SGM_BOX(R_)                                                                                        \
     case R_:                                                                                               \
-        if (g.NP == 1) hipLaunchKernelGGL((k_box_u8<R_, 1>), grid, block, 0, on, g, px, cp2, RB, band_lo);  \
-        else if (g.NP == 2) hipLaunchKernelGGL((k_box_u8<R_, 2>), grid, block, 0, on, g, px, cp2, RB, band_lo); \
-        else hipLaunchKernelGGL((k_box_u8<R_, 4>), grid, block, 0, on, g, px, cp2, RB, band_lo);            \
+        if (g.NP == 1) hipLaunchKernelGGL((k_box_u8<R_, 1>), grid, block, 0, on, g, px, cp2, RB);  \
+        else if (g.NP == 2) hipLaunchKernelGGL((k_box_u8<R_, 2>), grid, block, 0, on, g, px, cp2, RB); \
+        else hipLaunchKernelGGL((k_box_u8<R_, 4>), grid, block, 0, on, g, px, cp2, RB);            \
         break;
             switch (g.SW2) {
                 SGM_BOX(1)
@@ -612,8 +614,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // state; needs the 3-volume state buffer below the 4 GiB a 32-bit buffer offset reaches.
         // (At D = 64 the fused sweep is still ahead: 720p 0.35 against 0.39 ms, and 3 V of state.)
         const int GWs = (e->debug & 4) ? 64 : group_width(g, H);
-        // debug 8192: D <= 32 only (the round-1 limit; A/B)
-        const bool rows4 = GWs <= ((e->debug & 8192) ? 16 : 32) && e->sweep_rows <= 0 &&
+        const bool rows4 = GWs <= 32 && e->sweep_rows <= 0 &&
                            (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
         const int npass = g.mode == 1 ? 2 : 1;
         // Chained schedule (SGM_OPT_SCHEDULE 2, kernels_sweep.h: k_sweep_chain): no pre-pass; the bands of a sweep hand the
@@ -644,7 +645,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             KCHECK();
             if ((rc = stage_end(e, 1))) return rc;
             if ((rc = stage_begin(e, "cost_box"))) return rc;
-            launch_box(0, nvb, st);
+            launch_box(nvb, st);
             KCHECK();
             if ((rc = stage_end(e, 1))) return rc;
         } else {
@@ -663,7 +664,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         if ((rc = stage_end(e, 1))) return rc;
         if ((rc = stage_begin(e, "cost_vsum"))) return rc;
         if (g.SH2 >= 1 && g.SH2 <= 5) {
-            launch_vsum(0, nvb);
+            launch_vsum(nvb);
         } else {
             dim3 block(256), grid((unsigned)((g.rowsz / 8 + 255) / 256), (H + 63) / 64);
             hipLaunchKernelGGL(k_vsum, grid, block, 0, st, hsp, cp, H, g.rowsz, g.SH2, 64, g.hr);
@@ -744,33 +745,23 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 const int16_t *sin = sbuf ? sbuf + (size_t)(c & 1) * half : nullptr;
                 int16_t *sout = sbuf ? sbuf + (size_t)((c + 1) & 1) * half : nullptr;
 #define SGM_PRE(NP_, PART_) hipLaunchKernelGGL((k_prepass3<NP_, PART_>), grid, block, 0, on, g, xdir, ydir, C, bl, R, s0, s1, sin, sout, cpx)
-#define SGM_PRE2(NP_, PART_) hipLaunchKernelGGL((k_prepass3<NP_, PART_, 2>), grid, block, 0, on, g, xdir, ydir, C, bl, R, s0, s1, sin, sout, cpx)
-                // debug 16384: short prefetch blocks (fewer registers) for the pass that runs beside the sweep
-                const bool shortpb = g.NP == 2 && (e->debug & 16384) && on != st;
+                // (prefetch blocks of 2 rows for the pass that runs beside the sweep -- 70 registers instead of 106 -- were
+                // measured in round 2: within noise; that instantiation is gone)
                 if (g.NP == 1) { if (partial) SGM_PRE(1, true); else SGM_PRE(1, false); }
-                else if (shortpb) { if (partial) SGM_PRE2(2, true); else SGM_PRE2(2, false); }
                 else if (g.NP == 2) { if (partial) SGM_PRE(2, true); else SGM_PRE(2, false); }
                 else { if (partial) SGM_PRE(4, true); else SGM_PRE(4, false); }
 #undef SGM_PRE
-#undef SGM_PRE2
             };
             // roles of the pre-pass: 0 = predecessor one step earlier in the sweep's x order
             // (x - xdir), 1 = same column, 2 = one step later
             auto launch_prepass = [&](int xdir, int ydir, int16_t *bl, hipStream_t on) -> int {  // returns the launch count
                 if (rows4 && !(e->debug & 16)) {  // lane-grouped lines, state stored after every row
                     // one role per wave (grid.y = 3): these frames have too few lines to fill the SIMDs with
-                    // three-role waves (4K D=16: 478); debug 4096: the three roles fused in one wave (A/B)
-                    const bool split = !(e->debug & 4096);
-                    dim3 grid((g.W1 + 64 / GWs - 1) / (64 / GWs), split ? 3 : 1), block(64);
-#define SGM_PREG(GW_)                                                                                              \
-    do {                                                                                                           \
-        if (split) hipLaunchKernelGGL((k_prepass3_g<GW_, true>), grid, block, 0, on, g, xdir, ydir, C, bl);        \
-        else hipLaunchKernelGGL((k_prepass3_g<GW_, false>), grid, block, 0, on, g, xdir, ydir, C, bl);             \
-    } while (0)
-                    if (GWs == 8) SGM_PREG(8);
-                    else if (GWs == 16) SGM_PREG(16);
-                    else SGM_PREG(32);
-#undef SGM_PREG
+                    // three-role waves (4K D=16: 478)
+                    dim3 grid((g.W1 + 64 / GWs - 1) / (64 / GWs), 3), block(64);
+                    if (GWs == 8) hipLaunchKernelGGL((k_prepass3_g<8>), grid, block, 0, on, g, xdir, ydir, C, bl);
+                    else if (GWs == 16) hipLaunchKernelGGL((k_prepass3_g<16>), grid, block, 0, on, g, xdir, ydir, C, bl);
+                    else hipLaunchKernelGGL((k_prepass3_g<32>), grid, block, 0, on, g, xdir, ydir, C, bl);
                     return 1;
                 }
                 if (fused_prepass) {
@@ -886,7 +877,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                                                : (pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up"))))) return rc;
                 // per-row state written by the grouped pre-pass: role-major; by the single-direction kernel (debug 16): band layout
                 const int rmaj = (e->debug & 16) ? 0 : 1;
-                if (rows4 && !(e->debug & 4096)) {
+                if (rows4) {
                     // D <= 64, band height 1: the three directions from the previous row are element-wise given the
                     // pre-pass state of every row (k_vert3_g, one streaming pass over all pixels); only the in-row
                     // direction is a recurrence (k_rows_g, S +=)
@@ -902,18 +893,6 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     else SGM_VERT(32);
 #undef SGM_VERT
                     launch_rows_grouped(g, H, GWs, xdir, PATH_ACCUM, C, S, 1, wta, st);
-                } else if (rows4) {  // debug 4096: all four directions in one walk along the rows (round 1)
-                    dim3 grid((H + 64 / GWs - 1) / (64 / GWs)), block(64);
-                    const int16_t *bq = (const int16_t *)bl;
-#define SGM_ROWS4(GW_)                                                                                          \
-    do {                                                                                                        \
-        if (pass == 0) hipLaunchKernelGGL((k_rows4_g<GW_, PATH_FIRST>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
-        else hipLaunchKernelGGL((k_rows4_g<GW_, PATH_ACCUM>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
-    } while (0)
-                    if (GWs == 8) SGM_ROWS4(8);
-                    else if (GWs == 16) SGM_ROWS4(16);
-                    else SGM_ROWS4(32);
-#undef SGM_ROWS4
                 } else if (chain) {
                     if ((rc = launch_chain(g, a, fr, pass == 0 ? SWEEP_FIRST : SWEEP_ACCUM, chain_window(g, R, nbands, 1, e->chain_wgs), st))) return rc;
                 } else if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) {
@@ -1176,7 +1155,12 @@ int sgm_set_option(sgm_engine *e, int option, int value)
     else if (option == SGM_OPT_SCHEDULE) e->schedule = std::max(0, std::min(value, 2));
     else if (option == SGM_OPT_CHAIN_WGS) e->chain_wgs = std::max(0, value);
     else if (option == SGM_OPT_SWEEP_ROWS) e->sweep_rows = std::max(0, value);
-    else if (option == SGM_OPT_DEBUG) e->debug = value;
+    else if (option == SGM_OPT_DEBUG) {
+        // csrc/sgm_debug.h; bit 64 (the sweep's loader skips its loads: timing only, results WRONG) must be asked for twice
+        if ((value & SGM_DBG_SKIP_BOUNDARY_LOADS) && !(getenv("SGM_ALLOW_WRONG_RESULTS") && atoi(getenv("SGM_ALLOW_WRONG_RESULTS")) == 1))
+            return set_err(SGM_ERR_INVALID_ARG, "debug bit 64 makes results wrong (timing experiments only): set SGM_ALLOW_WRONG_RESULTS=1 to use it");
+        e->debug = value;
+    }
     else if (option == SGM_OPT_PREPASS_ROWS) e->prepass_rows = std::max(0, value);
     else return set_err(SGM_ERR_INVALID_ARG, "unknown option %d", option);
     return SGM_OK;
@@ -1406,12 +1390,16 @@ int sgm_pipeline_batch_device(sgm_engine *e, int N, const void *const *d_left, c
             }
         }
         if (joint && n > 1) {
-            // the peers start where `e`'s stream stands now (the caller's inputs may have been produced on it)
+            // cost stage of every pair on the stream of its own engine, from where `e`'s stream stands now (the caller's
+            // inputs may have been produced on it).  Side by side rather than one after the other: the per-pixel cost
+            // kernel is bound by the vector units, the box filter by HBM -- pairs in different kernels overlap (12 pairs
+            // 4K D=256: 7.2 against 7.4 ms per pair with the cost stages in one stream).
             HIP_TRY(hipEventRecord(e->ev_group, e->stream));
             for (int k = 1; k < n; k++) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, e->ev_group, 0));
             for (int k = 0; k < n && joint; k++) {
-                if ((rc = run_compute(eng[k], (const uint8_t *)d_left[i0 + k], (const uint8_t *)d_right[i0 + k], H, W, stride_bytes,
-                                      (int16_t *)d_disp_i16[i0 + k], PH_PRE))) {
+                rc = run_compute(eng[k], (const uint8_t *)d_left[i0 + k], (const uint8_t *)d_right[i0 + k], H, W, stride_bytes,
+                                 (int16_t *)d_disp_i16[i0 + k], PH_PRE);
+                if (rc) {
                     if (k == 0 && !e->plan_chain) {  // not a configuration for chained sweeps: nothing is enqueued yet but pair 0's cost stage
                         joint = false;
                         break;

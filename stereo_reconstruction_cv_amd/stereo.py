@@ -167,6 +167,14 @@ class Engine:
                                           rgb.ctypes.data if rgb is not None else None, C.byref(nv)))
         return (pts[:nv.value].copy(), rgb[:nv.value].copy() if rgb is not None else None)
 
+    def compact_points_device(self, d_xyz: int, d_dispf: int, d_colors: int | None, n: int, d_points: int,
+                              d_out_colors: int | None) -> int:
+        """Device-resident form (sgm_compact_points_device): valid points of one frame packed to the front of
+        d_points, in row-major order; returns their number (synchronises the engine's stream)."""
+        nv = C.c_int64(0)
+        _check(self._L.sgm_compact_points_device(self._h, d_xyz, d_dispf, d_colors, n, d_points, d_out_colors, C.byref(nv)))
+        return int(nv.value)
+
     def median3x3_host(self, img: np.ndarray) -> np.ndarray:
         img = np.ascontiguousarray(img, np.int16)
         out = np.empty_like(img)

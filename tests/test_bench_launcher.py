@@ -16,7 +16,8 @@ def _run(*extra, n=2):
     env = dict(os.environ, BENCH_MOCK="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "tiny",
+    wl = () if "--workload" in extra else ("--workload", "tiny")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *wl,
                         "--steps", "2", "--warmup", "1", *extra], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -29,8 +30,8 @@ def test_plain_start_with_two_gpus_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["world_size"] == 2 and d["config"]["frames_per_rank"] == [2, 2]
     assert d["config"]["global_pairs_per_step"] == 4 and d["config"]["ingest"] == "resident"
-    # the default run also exercises scatter -> compute -> gather once, outside the timed region
-    assert d["rccl_ingest_check"]["ok"] is True and d["rccl_ingest_check"]["frames"] == 4
+    # the default run also times the rank-0 ingest pipeline (scatter -> compute -> gather) after the timed region
+    assert d["ingest_rank0"]["ok"] is True and d["ingest_rank0"]["frames_per_step"] == 4 and d["ingest_rank0"]["pairs_per_s"] > 0
     assert "BENCH_MOCK" in d["data"]
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "roofline"):
         assert k in d
@@ -43,9 +44,17 @@ def test_rank0_ingest_mode_three_ranks():
     assert "rank 0 scatters" in d["config"]["parallelism"]
 
 
+def test_throughput_mode_workload_through_the_batch_entry():
+    env_n = 2
+    d = _run("--workload", "tinyt", n=env_n)
+    assert d["config"]["batch_entry"] is True and d["config"]["pairs_per_gpu_per_step"] == 3
+    assert d["config"]["frames_per_rank"] == [3, 3] and d["ingest_rank0"]["ok"] is True
+    assert "floor_bytes" in d and "unfused_model_bytes" in d and "frac_whole_step" not in d
+
+
 def test_single_gpu_path_needs_no_launcher():
     d = _run(n=1)
-    assert d["n_gpus"] == 1 and d["config"]["world_size"] == 1 and "rccl_ingest_check" not in d
+    assert d["n_gpus"] == 1 and d["config"]["world_size"] == 1 and "ingest_rank0" not in d
 
 
 def test_without_the_mock_and_without_a_gpu_it_fails_loudly():

@@ -1,5 +1,5 @@
 """World-size-2/3 gloo tests of the frame sharding layer (CPU; the compute is a stand-in since the
-HIP engine needs a GPU -- the sharding logic is what is under test)."""
+HIP engine needs a GPU -- the sharding, batching and pipelining logic is what is under test)."""
 import os
 import socket
 
@@ -43,14 +43,18 @@ def _fake_compute_pair(l, r):
     return d, torch.stack([d.float(), d.float() * 0.5, d.float() + 1.0], dim=-1)
 
 
+def _batches(n, steps):
+    g = torch.Generator().manual_seed(5)
+    return [(torch.randint(0, 256, (n, 6, 10), dtype=torch.uint8, generator=g),
+             torch.randint(0, 256, (n, 6, 10), dtype=torch.uint8, generator=g)) for _ in range(steps)]
+
+
 def _worker(rank, world, port, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = torch.Generator().manual_seed(5)
-        lefts = torch.randint(0, 256, (n, 6, 10), dtype=torch.uint8, generator=g)
-        rights = torch.randint(0, 256, (n, 6, 10), dtype=torch.uint8, generator=g)
+        lefts, rights = _batches(n, 1)[0]
         out = D.run_sharded(_fake_compute, lefts if rank == 0 else None, rights if rank == 0 else None)
         lo, hi = D.shard_range(n, rank, world)
         both = D.run_sharded(_fake_compute_pair, lefts if rank == 0 else None, rights if rank == 0 else None)
@@ -66,14 +70,19 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 5), (2, 4), (3, 2), (2, 1)])
-def test_scatter_compute_gather(world, n):
+def _spawn(target, world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, *args, q)) for r in range(world)]
     for p in procs:
         p.start()
+    return procs, q
+
+
+@pytest.mark.parametrize("world,n", [(2, 5), (2, 4), (3, 2), (2, 1)])
+def test_scatter_compute_gather(world, n):
+    procs, q = _spawn(_worker, world, n)
     msgs = [q.get(timeout=120) for _ in range(world + 1)]
     for p in procs:
         p.join(60)
@@ -82,3 +91,96 @@ def test_scatter_compute_gather(world, n):
     assert np.array_equal(res[1], res[2])
     spans = sorted((m[1], m[2], m[3]) for m in msgs if m[0] == "span")
     assert spans[0][1] == 0 and spans[-1][2] == n
+
+
+def _pipeline_worker(rank, world, port, n, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batches = _batches(n, steps)
+        order = []
+
+        def compute(l, r):
+            order.append(int(l.sum()) if l.numel() else -1)     # which shard this call saw
+            return _fake_compute_pair(l, r)
+
+        pipe = D.IngestPipeline(compute, src=0)
+        for l, r in batches:
+            pipe.step(l if rank == 0 else None, r if rank == 0 else None)
+            assert len(pipe.scattered) <= 1 and len(pipe.computed) <= 2 and len(pipe.gathering) <= 2   # two batches in flight, no more
+        res = pipe.drain()
+        # a second run through the same pipeline object (shape announced once, buffers reused)
+        for l, r in batches[:2]:
+            pipe.step(l if rank == 0 else None, r if rank == 0 else None)
+        res2 = pipe.drain()
+        if rank == 0:
+            assert len(res) == steps and len(res2) == min(2, steps)
+            for (l, r), (d, x) in zip(batches + batches[:2], res + res2):
+                wd, wx = _fake_compute_pair(l, r)
+                assert torch.equal(d, wd) and torch.equal(x, wx)       # every batch, in order, nothing mixed up
+        else:
+            assert res == [] and res2 == []
+        # every rank computed its own shard of every batch, in batch order
+        lo, hi = D.shard_range(n, rank, world)
+        assert order[:steps] == [int(l[lo:hi].sum()) if hi > lo else -1 for l, _ in batches]
+        q.put(("ok", rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,steps", [(2, 5, 4), (3, 4, 5), (2, 1, 3), (3, 7, 1), (2, 4, 2)])
+def test_ingest_pipeline_keeps_batches_in_order_under_overlap(world, n, steps):
+    """IngestPipeline: gather of batch k and scatter of batch k + 2 are posted around the compute of batch k + 1;
+    results must come back per batch, in order, for ragged shards (n not a multiple of the world size, ranks
+    with empty shards), any number of steps (fewer than the pipeline depth too), and on reuse."""
+    procs, q = _spawn(_pipeline_worker, world, n, steps)
+    msgs = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(m[1] for m in msgs) == list(range(world))
+
+
+def _compact_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(11)
+        npx = 40
+        pts_all = torch.rand((n, npx, 3), generator=g)
+        cnt_all = torch.randint(0, npx + 1, (n,), generator=g, dtype=torch.int64)
+        lo, hi = D.shard_range(n, rank, world)
+        out = D.gather_compacted(pts_all[lo:hi].clone(), cnt_all[lo:hi].clone(), n, dst=0)
+        if rank == 0:
+            outs, counts = out
+            assert torch.equal(counts, cnt_all)
+            for i in range(n):
+                assert torch.equal(outs[i], pts_all[i, :int(cnt_all[i])])
+        else:
+            assert out is None
+        q.put(("ok", rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 5), (3, 4)])
+def test_gather_of_compacted_point_lists(world, n):
+    procs, q = _spawn(_compact_worker, world, n)
+    msgs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len(msgs) == world
+
+
+def test_pipeline_single_process():
+    batches = _batches(3, 3)
+    pipe = D.IngestPipeline(_fake_compute)
+    for l, r in batches:
+        pipe.step(l, r)
+    res = pipe.drain()
+    assert len(res) == 3 and all(torch.equal(a, _fake_compute(l, r)) for a, (l, r) in zip(res, batches))

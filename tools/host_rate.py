@@ -42,3 +42,14 @@ for mode in (0, 1):
     dt = (time.perf_counter() - t0) / N
     assert all(np.array_equal(disps[i], disps[0]) for i in range(N))
     print(f"mode {mode}: compute_batch of {N} host pairs {dt * 1e3:.1f} ms/pair = {H * W * D / dt / 1e6:.0f} Mdisp/s")
+
+# the same entry in throughput mode (SGM_OPT_SCHEDULE 2: groups of 12 pairs share one chained sweep launch per pass)
+from stereo_reconstruction_cv_amd import _lib  # noqa: E402
+eng = cv.Engine(bench.sgbm_params(D, 7, 1))
+eng.set_option(_lib.SGM_OPT_SCHEDULE, 2)
+eng.compute_batch_host(L, R, None)
+t0 = time.perf_counter()
+disps = eng.compute_batch_host(L, R, None)
+dt = (time.perf_counter() - t0) / N
+assert all(np.array_equal(disps[i], disps[0]) for i in range(N))
+print(f"mode 1, throughput mode: compute_batch of {N} host pairs {dt * 1e3:.1f} ms/pair = {H * W * D / dt / 1e6:.0f} Mdisp/s")

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --workload W` into
-profiles/pmc_traffic.json: HBM traffic per stage of one frame, stamped with the hash of the kernel
-sources it was measured on (bench.py ignores the file when the stamp does not match its sources).
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --workload W` into an entry of
+profiles/pmc_traffic.json: HBM traffic per stage and PAIR, stamped with the hash of the kernel sources it was
+measured on (bench.py ignores the file when the stamp does not match its sources).
 
-    python tools/pmc_to_json.py WORKLOAD FETCH_DIR WRITE_DIR FRAMES BENCH_JSON OUT_JSON
+    python tools/pmc_to_json.py WORKLOAD FETCH_DIR WRITE_DIR BENCH_JSON OUT_JSON
 
 gfx950: FETCH_SIZE reports half of the streamed bytes (MI355X_MICROARCH.md, HBM), WRITE_SIZE is
-exact: traffic = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  FRAMES = steps + warmup of the
-profiled run.  A stage's traffic is the sum over the launches inside its HIP-event bracket."""
+exact: traffic = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  The number of pairs the profiled run
+processed comes from its own bench line: (steps + warmup) * pairs_per_gpu_per_step (run the passes with
+--no-latency-mode --no-cpu-baseline so that nothing else launches kernels).  A stage's traffic is the sum over
+the launches of its kernels.  OUT_JSON holds one entry per workload (entries measured on other sources are dropped)."""
 import csv
 import glob
 import json
@@ -24,8 +26,9 @@ STAGE_KERNEL = [  # stage -> regex on the demangled kernel name
     ("features", r"k_features"), ("cost_pix", r"k_pix(<|_px)"), ("cost_box", r"k_box_u8"),
     ("cost_hsum", r"k_hsum"), ("cost_vsum", r"k_vsum"),
     ("prepass", r"k_prepass3|k_path<\d+, \w+, 3"),
-    ("sweep_dn", r"k_sweep<\d+, \w+, 0|k_rows4_g<\d+, 0"), ("sweep_up", r"k_sweep<\d+, \w+, 1|k_rows4_g<\d+, 1"),
-    ("sweep_up_wta", r"k_sweep<\d+, \w+, 2"), ("path_W_wta", r"k_rows_g<\d+, \d+, \w+, 2"), ("path_W", r"k_rows_g<\d+, \d+, \w+, 1"),
+    ("chain_dn", r"k_sweep_chain<\d+, \w+, 0"), ("chain_up", r"k_sweep_chain<\d+, \w+, 1"),
+    ("sweep_dn", r"k_sweep<\d+, \w+, 0|k_vert3_g<\d+, 0"), ("sweep_up", r"k_sweep<\d+, \w+, 1|k_vert3_g<\d+, 1"),
+    ("sweep_up_wta", r"k_sweep<\d+, \w+, 2"), ("path_W_wta", r"k_rows_g<\d+, \d+, \w+, 2"), ("path_W", r"k_rows_g<\d+, \d+, \w+, [01]"),
     ("wta", r"k_wta_t"), ("select_lr", r"k_select"), ("median3", r"k_median3"), ("speckle", r"k_ccl_"),
     ("to_float", r"k_disp_to_float"), ("reproject", r"k_reproject"), ("post", r"k_post"), ("float_xyz", r"k_float_xyz"),
 ]
@@ -44,41 +47,55 @@ def collect(d, counter):
 
 
 def main():
-    wl, dfetch, dwrite, frames, bench_json, out = sys.argv[1:7]
-    frames = int(frames)
+    wl, dfetch, dwrite, bench_json, out = sys.argv[1:6]
     fetch, calls = collect(dfetch, "FETCH_SIZE")
     write, _ = collect(dwrite, "WRITE_SIZE")
     bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
+    cfg = bench["config"]
+    pairs = (bench["steps"] + bench["warmup"]) * cfg["pairs_per_gpu_per_step"]
     stage_ms = bench["stage_ms"]
     stages = {}
     for name in sorted(set(fetch) | set(write)):
-        b = (2.0 * fetch.get(name, 0.0) + write.get(name, 0.0)) * 1024.0 / frames
+        b = (2.0 * fetch.get(name, 0.0) + write.get(name, 0.0)) * 1024.0 / pairs
         for st, rx in STAGE_KERNEL:
             if re.search(rx, name):
+                # the in-row kernel of the small-D schedule runs inside the sweep stages; both pre-pass stages share one kernel
                 targets = [s for s in stage_ms if s.startswith("prepass")] if st == "prepass" else [st]
+                if st == "path_W" and "path_W" not in stage_ms:
+                    targets = [s for s in stage_ms if s.startswith("sweep")] or [st]
                 for t in targets:
-                    rec = stages.setdefault(t, {"kernels": [], "traffic_bytes_per_launch": 0.0, "launches_per_frame": 1,
-                                                "kernel_launches": 0})
+                    rec = stages.setdefault(t, {"kernels": [], "bytes_per_pair": 0.0, "kernel_launches_per_pair": 0.0})
                     rec["kernels"].append(name)
-                    rec["traffic_bytes_per_launch"] += b / len(targets)
-                    rec["kernel_launches"] += calls.get(name, 0) / frames / len(targets)
+                    rec["bytes_per_pair"] += b / len(targets)
+                    rec["kernel_launches_per_pair"] += calls.get(name, 0) / pairs / len(targets)
                 break
-    V = 2 * bench["config"]["height"] * (bench["config"]["width"] - bench["config"]["numDisparities"]) * bench["config"]["numDisparities"]
+    V = 2 * cfg["height"] * (cfg["width"] - cfg["numDisparities"]) * cfg["numDisparities"]
     for t, rec in stages.items():
-        rec["traffic_bytes_per_launch"] = int(rec["traffic_bytes_per_launch"])
-        rec["traffic_in_V"] = round(rec["traffic_bytes_per_launch"] / V, 3)
-        rec["stage_ms"] = stage_ms.get(t)
-        if stage_ms.get(t):
-            rec["GBps"] = round(rec["traffic_bytes_per_launch"] / (stage_ms[t] * 1e-3) / 1e9, 1)
-    total = sum(r["traffic_bytes_per_launch"] for r in stages.values())
-    json.dump({
-        "workload": wl, "source_stamp": source_stamp(), "frames_profiled": frames, "V_bytes": V,
-        "note": "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts half of streamed reads), per stage of one "
-                "frame = sum over the launches inside the stage's HIP-event bracket; separate --pmc passes; stage_ms/GBps "
-                "from the bench line of the FETCH pass (profiled runs are slower than unprofiled ones)",
-        "whole_frame_traffic_bytes": int(total), "whole_frame_traffic_in_V": round(total / V, 2),
-        "stages": stages}, open(out, "w"), indent=1)
-    print(f"{out}: {len(stages)} stages, whole frame {total / V:.2f} V = {total / 1e9:.1f} GB, stamp {source_stamp()}")
+        rec["bytes_per_pair"] = int(rec["bytes_per_pair"])
+        rec["traffic_in_V"] = round(rec["bytes_per_pair"] / V, 3)
+        rec["kernel_launches_per_pair"] = round(rec["kernel_launches_per_pair"], 3)
+    total = sum(r["bytes_per_pair"] for r in stages.values())
+    stamp = source_stamp()
+    doc = {}
+    if os.path.exists(out):
+        try:
+            doc = json.load(open(out))
+        except ValueError:
+            doc = {}
+    if doc.get("source_stamp") != stamp:
+        doc = {"source_stamp": stamp, "workloads": {}}
+    doc["note"] = ("traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts half of streamed reads), per stage and PAIR = sum "
+                   "over the launches of the stage's kernels / pairs the profiled run processed; separate --pmc passes "
+                   "(tools/profile_gpu.sh); V = 2*H*W1*D bytes")
+    doc["workloads"][wl] = {
+        "schedule": {"one kernel per direction": 0, "fused sweeps behind a boundary pre-pass (latency mode)": 1,
+                     "chained sweeps, no pre-pass (throughput mode)": 2}[cfg["schedule"]],
+        "batch": bool(cfg.get("batch_entry")), "pairs_profiled": pairs, "V_bytes": V,
+        "whole_pair_traffic_bytes": int(total), "whole_pair_traffic_in_V": round(total / V, 2),
+        "floor_bytes": bench.get("floor_bytes"), "traffic_over_floor": round(total / bench["floor_bytes"], 3) if bench.get("floor_bytes") else None,
+        "stages": stages}
+    json.dump(doc, open(out, "w"), indent=1)
+    print(f"{out}: {wl}: {len(stages)} stages, whole pair {total / V:.2f} V = {total / 1e9:.2f} GB, stamp {stamp}")
 
 
 if __name__ == "__main__":
