@@ -12,7 +12,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle_sgbm.so")
+# ORACLE_SANITIZE=1 (with libasan preloaded into the interpreter: tools/sanitize_oracle.sh) loads the
+# AddressSanitizer + UBSan build of the same sources instead
+_ASAN = os.environ.get("ORACLE_SANITIZE") == "1"
+_SO = os.path.join(_HERE, "liboracle_sgbm_asan.so" if _ASAN else "liboracle_sgbm.so")
 
 
 class Params(C.Structure):
@@ -33,7 +36,7 @@ def build(force: bool = False) -> str:
     stale = (not os.path.exists(_SO)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "liboracle_sgbm.so"],
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", os.path.basename(_SO)],
                        check=True, capture_output=True)
     return _SO
 

@@ -447,8 +447,12 @@ static int sgbm_core(const geom_t *g, const uint8_t *left, const uint8_t *right,
                     if (d < D) continue;
                     d = best;
                     /* right-view disparity, strictly-smaller-cost wins: A.6 step 3 */
+                    /* (best = -1 when every S of the pixel is saturated -- nothing is < MAX_COST: upstream then reads
+                     * disp2cost one element past the pixel's own column, for the right-most pixel one element past
+                     * the buffer; the comparison "> 32767" is false whatever is read, so skipping the read keeps
+                     * every value.  Found by the AddressSanitizer pass, tools/sanitize_oracle.sh.) */
                     int x2r = x + g->minX1 - d - g->minD;
-                    if (disp2cost[x2r] > minS) {
+                    if (d >= 0 && disp2cost[x2r] > minS) {
                         disp2cost[x2r] = (int16_t)minS;
                         disp2[x2r] = (int16_t)(d + g->minD);
                     }

@@ -137,3 +137,18 @@ def test_the_switch_that_makes_results_wrong_must_be_asked_for_twice():
     eng.set_option(_lib.SGM_OPT_DEBUG, 8)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert "SGM_OPT_DEBUG =" not in open(os.path.join(root, "include", "sgm_hip.h")).read()
+
+
+@pytest.mark.parametrize("schedule", [1, 0, 2])
+def test_every_cost_saturated_whole_map_invalid(schedule):
+    """Constant 0 against constant 255, 11x11 window, 8 paths, minDisparity < 0: every S saturates at 32767, upstream's
+    first-minimum scan keeps best = -1 and the map is invalid everywhere (tests/test_oracle_known_answers.py::
+    test_every_cost_saturated_at_the_right_most_pixel) -- the engine's "minS == MAX_COST" rejection must give the same."""
+    a = np.zeros((14, 64), np.uint8)
+    b = np.full((14, 64), 255, np.uint8)
+    p = dict(minDisparity=-3, numDisparities=16, blockSize=11, P1=10, P2=100, disp12MaxDiff=1, preFilterCap=63,
+             uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=1)
+    rep, t, h = U.compare_stages(a, b, p, schedule=schedule, sweep_rows=3 if schedule else 0)
+    assert t["headroom_ok"] and (t["S"] == 32767).all() and (t["disp"] == -64).all()
+    bad = [U.describe_mismatch(k, h[k], t[k]) for k, n in rep.items() if n]
+    assert not bad, "\n".join(bad)

@@ -150,3 +150,18 @@ def test_speckle_filter_needs_a_non_negative_range():
     zero = O.sgbm_compute(l, r, speckleWindowSize=100, speckleRange=0, **base)
     assert np.array_equal(neg, none)              # negative range: no filtering at all
     assert (zero == -16).sum() > (none == -16).sum()   # range 0 filters (only equal neighbours link)
+
+
+def test_every_cost_saturated_at_the_right_most_pixel():
+    """Constant 0 against constant 255 with an 11x11 window, 8 paths, minDisparity < 0: every S of every pixel saturates
+    at 32767, so the first-minimum scan keeps best = -1 (nothing is strictly smaller than MAX_COST) and the whole map is
+    invalid.  Upstream's right-view update then indexes one element past the row buffer for the right-most pixel (a
+    harmless comparison there); the restatement skips that read -- found by the sanitizer pass
+    (tools/sanitize_oracle.sh runs this file under AddressSanitizer + UBSan)."""
+    a = np.zeros((14, 64), np.uint8)
+    b = np.full((14, 64), 255, np.uint8)
+    p = dict(minDisparity=-3, numDisparities=16, blockSize=11, P1=10, P2=100, disp12MaxDiff=1, preFilterCap=63,
+             uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=1)
+    d, t = O.sgbm_compute(a, b, taps=True, **p)
+    assert t["headroom_ok"] and (t["S"] == 32767).all()
+    assert (d == (-3 - 1) * 16).all()

@@ -1,3 +1,21 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_r03b.log 2>&1; tail -5 gpurun_out/pytest_gpu_r03b.log
-timeout -k 10 300 python bench.py --stages > gpurun_out/bench_default_r03b.json 2> gpurun_out/bench_default_r03b.err; tail -20 gpurun_out/bench_default_r03b.err; cat gpurun_out/bench_default_r03b.json | cut -c1-3000
+run() {
+  echo "== $* (GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES)"
+  timeout -k 10 300 python bench.py --workload $1 $2 $3 --no-cpu-baseline --no-latency-mode 2>&1 | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('ms/step',round(d['ms_per_step'],3),'ms/pair',round(d['ms_per_pair'],3),'pairs/s',round(d['pairs_per_s'],2))
+"
+}
+run c1x8
+run c1x16
+run c4
+export GPU_MAX_HW_QUEUES=8
+run c1x8
+run c1x16
+run c4
+export GPU_MAX_HW_QUEUES=16
+run c1x16
+run c4
+run c3c5x3
