@@ -46,7 +46,7 @@ struct SweepArgs {
 
 // Frames of one chained launch (sgm_pipeline_batch_device: several pairs per launch, so that the GPU is full although
 // one frame's chain keeps only T / LAG workgroups busy).  Tickets go round the frames: ticket t = band t / nf of frame t % nf.
-constexpr int CHAIN_MAX_FRAMES = 16;
+constexpr int CHAIN_MAX_FRAMES = 32;
 struct ChainFrames {
     int nf;
     const int16_t *C[CHAIN_MAX_FRAMES];
@@ -155,6 +155,11 @@ struct ChainWait {
 };
 
 // ==== loader wave: state of the row above the band, HBM -> registers -> LDS ring 0, ahead of wave 0 ====
+// Blocks of LB pixels: the loads of block b + 1 are issued when the first pixel of block b goes to the ring, LB / PPS
+// lockstep steps before their first use.  Plain schedule: LB = ring depth (4 steps of prefetch distance: the record was
+// written by an earlier kernel and is anywhere in HBM).  Chained schedule: LB = half the ring (2 steps) -- the band must
+// not run further ahead of the band above than it has to (every step of lag is a step of chain latency per band), and
+// the record it reads was written a few microseconds ago.
 template <int NP, bool PARTIAL, bool CHAIN>
 __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs &a, int band, int lane, uint32_t *lds)
 {
@@ -163,7 +168,11 @@ __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs
     constexpr int LDAUX = CHAIN ? 16 : (SGM_NT_SWEEP_LOADS ? 2 : 0);
     constexpr int PPS = sweep_pps(NP);
     constexpr int RING = sweep_ring(NP);
-    constexpr int PB = RING;  // prefetch block (pixels) = ring depth, so slot(k) = k % PB is static
+    constexpr int LB = CHAIN ? RING / 2 : RING;  // pixels per prefetch block
+    // first ring slot of a block: slot(k) = k % RING is static because blocks alternate between the two register
+    // buffers: bA holds the blocks that start at multiples of 2 LB, bB the others
+    constexpr int OFF_A = 0, OFF_B = LB % RING;
+    static_assert(2 * PPS <= LB && LB % PPS == 0 && RING % LB == 0, "prologue writes 2 * PPS pixels of block 0");
     constexpr int SLOT = sweep_slot_dwords(NP);
     constexpr int ROLE = 64 * NP;  // dwords per role inside a slot
     const int R = a.R;
@@ -175,7 +184,7 @@ __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs
     uint32_t *const ring0 = lds + lane * NP;
 
     const bool has_prev = band > 0 && !(a.dbg & 64);
-    Pack<NP> bA[PB][3], bB[PB][3];
+    Pack<NP> bA[LB][3], bB[LB][3];
     // this band's boundary row as a buffer resource: [x][3 roles][D] int16
     const int row_bytes = W1 * 3 * D * 2;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -194,9 +203,9 @@ __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs
     // workgroup waits for HBM latency every block)
     auto lb_t = [&](auto full_c, Pack<NP>(*b)[3], int k0) {
         constexpr bool FULL = decltype(full_c)::value;
-        if (CHAIN) cw.step((uint32_t)min(k0 + PB, W1));  // (a block past the row's end waits for nothing new)
+        if (CHAIN) cw.step((uint32_t)min(k0 + LB, W1));  // (a block past the row's end waits for nothing new)
 #pragma unroll
-        for (int u = 0; u < PB; u++) {
+        for (int u = 0; u < LB; u++) {
             if (FULL || k0 + u < W1) {
                 const int so = p0 + (k0 + u) * pk;
 #pragma unroll
@@ -204,10 +213,10 @@ __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs
             }
         }
     };
-    auto wb_t = [&](auto full_c, Pack<NP>(*b)[3], int u, int k) {  // pixel k, k % PB == u
+    auto wb_t = [&](auto full_c, Pack<NP>(*b)[3], int off, int u, int k) {  // pixel k = u-th of its block, ring slot off + u
         constexpr bool FULL = decltype(full_c)::value;
         if (!FULL && k > W1) return;
-        uint32_t *slot = ring0 + u * SLOT;
+        uint32_t *slot = ring0 + (off + u) * SLOT;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             Pack<NP> v;
@@ -233,72 +242,72 @@ __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs
     const std::true_type full{};
     const std::false_type part{};
     // prologue: pixels 0 .. 2*PPS-1, then the rest of block 0
-    if (2 * PB <= W1) {
+    if (2 * LB <= W1) {
         lb_t(full, bA, 0);
-        lb_t(full, bB, PB);
+        lb_t(full, bB, LB);
 #pragma unroll
-        for (int p = 0; p < 2 * PPS; p++) wb_t(full, bA, p, p);
+        for (int p = 0; p < 2 * PPS; p++) wb_t(full, bA, OFF_A, p, p);
         wg_barrier();
 #pragma unroll
-        for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) {
+        for (int u0 = 2 * PPS; u0 < LB; u0 += PPS) {
 #pragma unroll
-            for (int p = 0; p < PPS; p++) wb_t(full, bA, u0 + p, u0 + p);
+            for (int p = 0; p < PPS; p++) wb_t(full, bA, OFF_A, u0 + p, u0 + p);
             wg_barrier();
             t++;
         }
     } else {
         lb_t(part, bA, 0);
-        lb_t(part, bB, PB);
+        lb_t(part, bB, LB);
 #pragma unroll
-        for (int p = 0; p < 2 * PPS; p++) wb_t(part, bA, p, p);
+        for (int p = 0; p < 2 * PPS; p++) wb_t(part, bA, OFF_A, p, p);
         wg_barrier();
 #pragma unroll
-        for (int u0 = 2 * PPS; u0 < PB; u0 += PPS) {
+        for (int u0 = 2 * PPS; u0 < LB; u0 += PPS) {
             if (t < T) {
 #pragma unroll
-                for (int p = 0; p < PPS; p++) wb_t(part, bA, u0 + p, u0 + p);
+                for (int p = 0; p < PPS; p++) wb_t(part, bA, OFF_A, u0 + p, u0 + p);
                 wg_barrier();
                 t++;
             }
         }
     }
-    int k0 = PB;  // bB holds block [k0, k0+PB), bA is free
-    // steady state: blocks k0 (in bB), k0+PB (to bA), k0+2PB (to bB) all full -> straight-line
-    for (; k0 + 3 * PB <= W1; k0 += 2 * PB) {
-        lb_t(full, bA, k0 + PB);
+    int k0 = LB;  // bB holds block [k0, k0+LB), bA is free
+    // steady state: blocks k0 (in bB), k0+LB (to bA), k0+2LB (to bB) all full -> straight-line
+    for (; k0 + 3 * LB <= W1; k0 += 2 * LB) {
+        lb_t(full, bA, k0 + LB);
 #pragma unroll
-        for (int u0 = 0; u0 < PB; u0 += PPS) {
+        for (int u0 = 0; u0 < LB; u0 += PPS) {
 #pragma unroll
-            for (int p = 0; p < PPS; p++) wb_t(full, bB, u0 + p, k0 + u0 + p);
+            for (int p = 0; p < PPS; p++) wb_t(full, bB, OFF_B, u0 + p, k0 + u0 + p);
             wg_barrier();
         }
-        lb_t(full, bB, k0 + 2 * PB);
+        lb_t(full, bB, k0 + 2 * LB);
 #pragma unroll
-        for (int u0 = 0; u0 < PB; u0 += PPS) {
+        for (int u0 = 0; u0 < LB; u0 += PPS) {
 #pragma unroll
-            for (int p = 0; p < PPS; p++) wb_t(full, bA, u0 + p, k0 + PB + u0 + p);
+            for (int p = 0; p < PPS; p++) wb_t(full, bA, OFF_A, u0 + p, k0 + LB + u0 + p);
             wg_barrier();
         }
-        t += 2 * (PB / PPS);
+        t += 2 * (LB / PPS);
     }
     // tail: guarded blocks, then idle steps until every row has finished
-    for (; t < T; k0 += 2 * PB) {
-        lb_t(part, bA, k0 + PB);
+    for (; t < T; k0 += 2 * LB) {
+        lb_t(part, bA, k0 + LB);
 #pragma unroll
-        for (int u0 = 0; u0 < PB; u0 += PPS) {
+        for (int u0 = 0; u0 < LB; u0 += PPS) {
             if (t < T) {
 #pragma unroll
-                for (int p = 0; p < PPS; p++) wb_t(part, bB, u0 + p, k0 + u0 + p);
+                for (int p = 0; p < PPS; p++) wb_t(part, bB, OFF_B, u0 + p, k0 + u0 + p);
                 wg_barrier();
                 t++;
             }
         }
-        lb_t(part, bB, k0 + 2 * PB);
+        lb_t(part, bB, k0 + 2 * LB);
 #pragma unroll
-        for (int u0 = 0; u0 < PB; u0 += PPS) {
+        for (int u0 = 0; u0 < LB; u0 += PPS) {
             if (t < T) {
 #pragma unroll
-                for (int p = 0; p < PPS; p++) wb_t(part, bA, u0 + p, k0 + PB + u0 + p);
+                for (int p = 0; p < PPS; p++) wb_t(part, bA, OFF_A, u0 + p, k0 + LB + u0 + p);
                 wg_barrier();
                 t++;
             }
@@ -515,12 +524,15 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
 // grid size, any dispatch order, and with other kernels sharing the GPU; a workgroup waits only for a lower
 // ticket of its own launch.  Barrier counts are those of k_sweep: 1 + T per band for every wave.
 //
-// What it costs.  A band trails the band above by LAG = 2 (R - 1) + about 15 steps, so a single frame's
-// pass is a chain of nbands * LAG + T steps (4K, D = 256, R = 11: about 8600 steps against T = 1812 for the
-// plain sweep) on T / LAG = about 50 workgroups: slower for one frame, but a frame needs only that many
-// CUs, and with several frames in flight (sgm_compute_batch, bench.py workloads with several streams) the
-// GPU is full without any pre-pass.
-constexpr int CHAIN_KD = 3;  // a store is taken to be complete when the stores of KD later steps have been issued *and counted*: see chain_publisher_wave
+// What it costs.  A band trails the band above by LAG = 2 (R - 1) + about 11 steps (LDS hand-off to the publisher 1,
+// CHAIN_KD 3, the loader's poll one block old 2, a whole block published 2, loaded one block ahead 2, ring lead 1), so
+// a single frame's pass is a chain of nbands * LAG + T steps (4K, D = 256, R = 12: about 7800 steps against T = 1814
+// for the plain sweep) on T / LAG = about 55 workgroups: slower for one frame, but a frame needs only that many CUs,
+// and with several frames in one launch (sgm_pipeline_batch_device) the GPU is full without any pre-pass.
+#ifndef SGM_CHAIN_KD
+#define SGM_CHAIN_KD 3
+#endif
+constexpr int CHAIN_KD = SGM_CHAIN_KD;  // a store is taken to be complete when the stores of KD later steps have been issued *and counted*: see chain_publisher_wave
 
 template <int NP, bool PARTIAL>
 __device__ __forceinline__ void chain_publisher_wave(const Geom &g, const SweepArgs &a, int band, int lane, uint32_t *lds)
