@@ -70,6 +70,7 @@ WORKLOADS = {
                 "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch"),
     "c5x12": (2160, 3840, 256, 7, 0, 12, True, 2, True, "batch of twelve 4K D=256 5-path pairs per step + reproject, throughput mode"),
     "c4t": (1080, 1920, 128, 7, 0, 16, False, 2, True, "batch of sixteen 1920x1080 D=128 5-path pairs per step, throughput mode"),
+    "c4t32": (1080, 1920, 128, 7, 0, 32, False, 2, True, "batch of 32 1920x1080 D=128 5-path pairs per step, throughput mode"),
     "nb": (2160, 3840, 16, 11, 0, 1, True, 1, False, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
     "tiny": (96, 480, 64, 7, 1, 2, True, 1, False, "96x480 D=64 MODE_HH x2 (launcher rehearsal only, not a BASELINE config)"),
     "tinyt": (96, 480, 128, 7, 1, 3, True, 2, True, "96x480 D=128 MODE_HH x3, throughput mode (launcher rehearsal only)"),

@@ -156,10 +156,15 @@ struct ChainWait {
 
 // ==== loader wave: state of the row above the band, HBM -> registers -> LDS ring 0, ahead of wave 0 ====
 // Blocks of LB pixels: the loads of block b + 1 are issued when the first pixel of block b goes to the ring, LB / PPS
-// lockstep steps before their first use.  Plain schedule: LB = ring depth (4 steps of prefetch distance: the record was
-// written by an earlier kernel and is anywhere in HBM).  Chained schedule: LB = half the ring (2 steps) -- the band must
-// not run further ahead of the band above than it has to (every step of lag is a step of chain latency per band), and
-// the record it reads was written a few microseconds ago.
+// lockstep steps before their first use.  LB = ring depth (4 steps of prefetch distance) in both schedules.  For the
+// chained schedule half-ring blocks (2 steps) were measured in round 3 -- every step a band runs less far ahead of what
+// it needs is a step less of chain latency per band: a launch that is bound by that latency gained (16 pairs 1080p
+// D=128: 6.65 -> 5.99 ms), the default batch lost (12 pairs 4K D=256: 23.6 -> 25.5 and 29.7 -> 30.4 ms per pass): with
+// the GPU saturated the record's loads take longer than two steps to come back and the whole lockstep workgroup waits
+// for them.  SGM_CHAIN_HALF_BLOCKS=1 builds that variant.
+#ifndef SGM_CHAIN_HALF_BLOCKS
+#define SGM_CHAIN_HALF_BLOCKS 0
+#endif
 template <int NP, bool PARTIAL, bool CHAIN>
 __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs &a, int band, int lane, uint32_t *lds)
 {
@@ -168,7 +173,7 @@ __device__ __forceinline__ void sweep_loader_wave(const Geom &g, const SweepArgs
     constexpr int LDAUX = CHAIN ? 16 : (SGM_NT_SWEEP_LOADS ? 2 : 0);
     constexpr int PPS = sweep_pps(NP);
     constexpr int RING = sweep_ring(NP);
-    constexpr int LB = CHAIN ? RING / 2 : RING;  // pixels per prefetch block
+    constexpr int LB = (CHAIN && SGM_CHAIN_HALF_BLOCKS) ? RING / 2 : RING;  // pixels per prefetch block
     // first ring slot of a block: slot(k) = k % RING is static because blocks alternate between the two register
     // buffers: bA holds the blocks that start at multiples of 2 LB, bB the others
     constexpr int OFF_A = 0, OFF_B = LB % RING;
@@ -524,10 +529,10 @@ __global__ __launch_bounds__(SWEEP_MAX_ROWS * 64 + 64) void k_sweep(Geom g, Swee
 // grid size, any dispatch order, and with other kernels sharing the GPU; a workgroup waits only for a lower
 // ticket of its own launch.  Barrier counts are those of k_sweep: 1 + T per band for every wave.
 //
-// What it costs.  A band trails the band above by LAG = 2 (R - 1) + about 11 steps (LDS hand-off to the publisher 1,
-// CHAIN_KD 3, the loader's poll one block old 2, a whole block published 2, loaded one block ahead 2, ring lead 1), so
-// a single frame's pass is a chain of nbands * LAG + T steps (4K, D = 256, R = 12: about 7800 steps against T = 1814
-// for the plain sweep) on T / LAG = about 55 workgroups: slower for one frame, but a frame needs only that many CUs,
+// What it costs.  A band trails the band above by LAG = 2 (R - 1) + about 17 steps (LDS hand-off to the publisher 1,
+// CHAIN_KD 3, the loader's poll one block old 4, a whole block published 4, loaded one block ahead 4, ring lead 1), so
+// a single frame's pass is a chain of nbands * LAG + T steps (4K, D = 256, R = 12: about 8800 steps against T = 1814
+// for the plain sweep) on T / LAG = about 47 workgroups: slower for one frame, but a frame needs only that many CUs,
 // and with several frames in one launch (sgm_pipeline_batch_device) the GPU is full without any pre-pass.
 #ifndef SGM_CHAIN_KD
 #define SGM_CHAIN_KD 3

@@ -382,12 +382,12 @@ static int launch_chain(const Geom &g, const SweepArgs &a, const ChainFrames &fr
     if (g.NP == 2) return partial ? launch_chain_np<2, true>(g, a, fr, mode, wgs, st) : launch_chain_np<2, false>(g, a, fr, mode, wgs, st);
     return partial ? launch_chain_np<4, true>(g, a, fr, mode, wgs, st) : launch_chain_np<4, false>(g, a, fr, mode, wgs, st);
 }
-// workgroups of a chained launch over nf frames: a band trails the band above by about 2 (R - 1) + 12 lockstep steps and
+// workgroups of a chained launch over nf frames: a band trails the band above by about 2 (R - 1) + 17 lockstep steps and
 // lasts T steps, so a frame keeps about T / lag workgroups busy; more would only wait (and hold CUs)
 static int chain_window(const Geom &g, int R, int nbands, int nf, int override_wgs)
 {
     const int pps = sweep_pps(g.NP);
-    const int T = (g.W1 + pps - 1) / pps + 2 * (R - 1), lag = 2 * (R - 1) + 12;
+    const int T = (g.W1 + pps - 1) / pps + 2 * (R - 1), lag = 2 * (R - 1) + 17;
     const int per_frame = override_wgs > 0 ? override_wgs : std::max(4, (T + lag - 1) / lag);
     return (int)std::min<int64_t>({(int64_t)per_frame * nf, (int64_t)nbands * nf, 256});
 }

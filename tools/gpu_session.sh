@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_chain.py tests/test_gpu_paths.py -x -q 2>&1 | tail -3
 run() {
-  echo "== $*"
+  echo "== $* (GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES)"
   timeout -k 10 300 python bench.py --workload $1 $2 $3 $4 $5 --stages --no-cpu-baseline --no-latency-mode 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
@@ -11,7 +10,11 @@ for l in sys.stdin:
 "
 }
 run c3c5x12
-run c3c5x6
 run c4t
-run c5x12
-run c3c5 --schedule 2
+run c4t32
+export GPU_MAX_HW_QUEUES=8
+run c3c5x12
+run c4t32
+export GPU_MAX_HW_QUEUES=16
+run c3c5x12
+run c4t32
