@@ -46,10 +46,29 @@ def collect(d, counter):
     return tot, calls
 
 
+def from_summary(path):
+    """the same totals from a pmc_fetch_write_summary.txt (tools/pmc_summary.py: per kernel {counter: (launches, average)})"""
+    fetch, write, calls = defaultdict(float), defaultdict(float), defaultdict(int)
+    for line in open(path):
+        name, _, rest = line.partition(" {")
+        if not rest:
+            continue
+        rec = eval("{" + rest)  # noqa: S307 -- our own summary file
+        if "FETCH_SIZE" in rec:
+            fetch[name] = rec["FETCH_SIZE"][0] * rec["FETCH_SIZE"][1]
+            calls[name] = rec["FETCH_SIZE"][0]
+        if "WRITE_SIZE" in rec:
+            write[name] = rec["WRITE_SIZE"][0] * rec["WRITE_SIZE"][1]
+    return fetch, write, calls
+
+
 def main():
     wl, dfetch, dwrite, bench_json, out = sys.argv[1:6]
-    fetch, calls = collect(dfetch, "FETCH_SIZE")
-    write, _ = collect(dwrite, "WRITE_SIZE")
+    if dfetch.endswith(".txt"):      # a kept summary instead of the raw passes (FETCH_DIR = WRITE_DIR = the summary file)
+        fetch, write, calls = from_summary(dfetch)
+    else:
+        fetch, calls = collect(dfetch, "FETCH_SIZE")
+        write, _ = collect(dwrite, "WRITE_SIZE")
     bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
     cfg = bench["config"]
     pairs = (bench["steps"] + bench["warmup"]) * cfg["pairs_per_gpu_per_step"]

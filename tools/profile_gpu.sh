@@ -11,6 +11,9 @@ TAG=${1:-r03}
 shift
 WLS=${@:-c3c5x12}
 B="--no-cpu-baseline --no-latency-mode"
+# entries of earlier calls (gpurun_out/ does not travel to the box; profiles/ does): keep them if the sources still match
+mkdir -p $R/gpurun_out/prof_$TAG
+[ -f $R/gpurun_out/prof_$TAG/pmc_traffic.json ] || cp $R/profiles/pmc_traffic.json $R/gpurun_out/prof_$TAG/pmc_traffic.json 2>/dev/null
 for WL in $WLS; do
     O=$R/gpurun_out/prof_$TAG/$WL
     mkdir -p $O
