@@ -93,3 +93,29 @@ def test_batch_entry_shares_one_chained_launch(H, W, D, bs, mode, rows, N):
             x = dx[i].cpu().numpy()
             fin = np.isfinite(ref)
             assert np.array_equal(np.isfinite(x), fin) and np.array_equal(x[fin], ref[fin]), (rep, i)
+
+
+def test_sharded_compute_returns_compacted_point_lists():
+    """dist.hip_batch_compute(compact=True): what a rank hands to dist.gather_compacted instead of the dense XYZ image --
+    the valid points of every frame (main.ipynb:726-737: finite X and disparity > 0) packed to the front of its row, in
+    row-major order, with their count; equal to numpy boolean indexing on the oracle's XYZ."""
+    import torch
+    from stereo_reconstruction_cv_amd import dist as D_
+    H, W, D, N = 60, 420, 128, 3
+    p = U.params(D, 7, 0, 1, speckleWindowSize=30, speckleRange=2)
+    Q = synth.default_Q(W)
+    pairs = [synth.make_pair(H, W, D, 900 + i)[:2] for i in range(N)]
+    L = torch.from_numpy(np.stack([a for a, _ in pairs])).cuda()
+    R = torch.from_numpy(np.stack([b for _, b in pairs])).cuda()
+    for schedule in (1, 2):
+        disp, pts, counts = D_.hip_batch_compute(p, Q, schedule=schedule, compact=True)(L, R)
+        assert pts.shape == (N, H * W, 3) and counts.shape == (N,)
+        for i, (a, b) in enumerate(pairs):
+            want = O.sgbm_compute(a, b, **p)
+            assert np.array_equal(disp[i].cpu().numpy(), want)
+            f = O.disp_to_float(want)
+            xyz = O.reproject(f, Q)
+            mask = O.valid_mask(xyz, f)
+            n = int(counts[i])
+            assert n == int(mask.sum()) and n > 0
+            assert np.array_equal(pts[i, :n].cpu().numpy(), xyz[mask])
