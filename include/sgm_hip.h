@@ -22,7 +22,11 @@
  *                                                                    gui.py:160-161, main.ipynb cell 7
  *   sgm_remap_linear_u8  <- cv2.remap(img, map1, map2, interpolation=cv2.INTER_LINEAR)
  *                                                                    gui.py:163-164, main.ipynb cell 7
- *   sgm_compute_batch    <- the same, over N independent pairs (frame sharding unit)
+ *   sgm_compute_batch,
+ *   sgm_pipeline_batch_device
+ *                        <- cell c13 over N independent pairs (BASELINE config 4: a batch per GPU;
+ *                           the frame sharding unit).  With SGM_OPT_SCHEDULE = 2 ("throughput mode")
+ *                           the pairs of a batch share one chained sweep launch per pass     main.ipynb:780-797
  *   sgm_get_headroom     <- (no counterpart) tells the caller whether the last compute stayed inside
  *                           the int16 regime in which OpenCV's own arithmetic is exact
  *
@@ -181,7 +185,7 @@ int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, 
                         void *d_disp_f32, void *d_xyz_f32);
 /* The driver cell over N resident pairs (BASELINE config 4: a batch of pairs per GPU; main.ipynb:780-797 once per pair),
  * throughput mode: arrays of N device pointers (d_disp_f32 / d_xyz_f32 may be NULL).  With SGM_OPT_SCHEDULE = 2 the
- * pairs share ONE chained sweep launch per pass (groups of up to 16 pairs on internal engines: about 12 GB of device
+ * pairs share ONE chained sweep launch per pass (groups of up to 32 pairs on internal engines: about 13 GB of device
  * memory per 4K D=256 pair of a group); otherwise pair after pair.  Results equal N calls of sgm_pipeline_device.
  * Asynchronous: sgm_synchronize(e) waits for all of it. */
 int sgm_pipeline_batch_device(sgm_engine *e, int N, const void *const *d_left, const void *const *d_right, int H, int W,
