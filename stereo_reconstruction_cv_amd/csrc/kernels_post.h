@@ -97,20 +97,22 @@ __global__ __launch_bounds__(256) void k_add_sat(int16_t *__restrict__ S, const 
 // LG = log2(chunks per row) when D is a power of two (16..512): compile-time trip counts, the next
 // block's loads prefetched into registers during the current block's scan.  LG = -1: any D
 // (multiple of 16), plain staging.
-// TWO: the costs are the saturating sum of two volumes, S + S2 (MODE_SGBM with D <= 128: the fifth path runs
-// beside the sweep into a volume of its own; every path cost is >= 0 and the sum saturates, so the order of
-// the additions does not matter -- kernels_path.h).
-template <bool POSW, int LG, bool TWO = false>
+// NV: the costs are the saturating sum of NV volumes.  2: S + S2 (MODE_SGBM with D <= 128: the fifth path runs
+// beside the sweep into a volume of its own); 3: S + S2 + S3 (D <= 64: both in-row paths run beside the per-row
+// pre-pass and the element-wise vertical kernel, each into a volume of its own).  Every path cost is >= 0 and the
+// sum saturates, so the order of the additions does not matter -- kernels_path.h.
+template <bool POSW, int LG, int NV = 1>
 __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict__ S, uint2 *__restrict__ wta, int64_t npix,
-                                              const int16_t *__restrict__ S2 = nullptr)
+                                              const int16_t *__restrict__ S2 = nullptr, const int16_t *__restrict__ S3 = nullptr)
 {
+    constexpr bool TWO = NV >= 2, THREE = NV >= 3;
     extern __shared__ __attribute__((aligned(16))) uint8_t rows[];
     const int lane = threadIdx.x, D = LG >= 0 ? (8 << LG) : g.D, W1 = g.W1;
     const int stride = wta_t_stride(D);
     const int cpr = D * 2 / 16;  // 16-byte chunks per pixel row; a lane moves cpr chunks per block
     const int64_t nblocks = (npix + 63) / 64;
     constexpr int PF = LG < 0 ? 8 : (LG >= 5 ? 32 : (1 << LG));  // chunks per lane held in registers
-    uint4 v[PF], v2[TWO ? PF : 1];
+    uint4 v[PF], v2[TWO ? PF : 1], v3[THREE ? PF : 1];
     // chunk c = lane + 64 k of the block's contiguous 64 * D * 2 bytes: loads with a clamped index
     // (no branch between them), committed to the padded LDS rows afterwards
     auto issue = [&](int64_t blk, int k0) {
@@ -124,6 +126,11 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
 #pragma unroll
             for (int u = 0; u < PF; u++) v2[u] = src2[min(lane + 64 * (k0 + u), total - 1)];
         }
+        if constexpr (THREE) {
+            const uint4 *src3 = reinterpret_cast<const uint4 *>(S3 + blk * 64 * D);
+#pragma unroll
+            for (int u = 0; u < PF; u++) v3[u] = src3[min(lane + 64 * (k0 + u), total - 1)];
+        }
     };
     auto summed = [&](int u) {  // chunk u of the cost rows: S, or sat(S + S2)
         uint4 r = v[u];
@@ -132,6 +139,12 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
             r.y = pk_adds_s(r.y, v2[u].y);
             r.z = pk_adds_s(r.z, v2[u].z);
             r.w = pk_adds_s(r.w, v2[u].w);
+        }
+        if constexpr (THREE) {
+            r.x = pk_adds_s(r.x, v3[u].x);
+            r.y = pk_adds_s(r.y, v3[u].y);
+            r.z = pk_adds_s(r.z, v3[u].z);
+            r.w = pk_adds_s(r.w, v3[u].w);
         }
         return r;
     };

@@ -107,6 +107,8 @@ struct sgm_engine {
     bool own_stream = false;
     hipStream_t aux = nullptr;            // second stream: MODE_HH overlaps the upward pre-pass with the downward sweep
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux2 = nullptr;           // third stream (D <= 64, MODE_SGBM: the left-to-right in-row path beside everything else)
+    hipEvent_t ev_join2 = nullptr;
     int keep_aggr = 0;
     int profile = 0;
     int schedule = 1;    // 0: one kernel per direction (v1); 1: fused 4-direction sweeps; 2: chained sweeps, no pre-pass (throughput mode)
@@ -132,6 +134,7 @@ struct sgm_engine {
     DevBuf lrec, rplanes;               // features
     DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
     DevBuf aggr2;                       // MODE_SGBM, D <= 128: the fifth path's own volume (added to S by the winner-take-all)
+    DevBuf aggr3;                       // MODE_SGBM, D <= 64: the other in-row path's own volume
     DevBuf wta;                         // uint2 [H][W]
     DevBuf bndL, bndL2;                 // band-boundary state of the sweep pre-pass (down / up)
     DevBuf pstate, pstate2;             // line state between the row chunks of the pre-pass (ping-pong, down / up)
@@ -827,6 +830,16 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 if ((rc = e->aggr2.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
                 S2 = (int16_t *)e->aggr2.p;
             }
+            // D <= 64 (small-D schedule): the OTHER in-row path (left to right) needs nothing but C either.  It used to follow
+            // the element-wise vertical kernel as "S +=" on the main stream -- a chain of W1 dependent steps on the
+            // critical path of a latency-bound frame; now it runs as a FIRST pass into a third volume on a stream of its
+            // own, beside the per-row pre-pass and k_vert3_g, and the winner-take-all adds three volumes.
+            const bool three_vol = two_vol && rows4 && !(e->debug & SGM_DBG_IN_ROW_ON_MAIN_STREAM);
+            int16_t *S3 = nullptr;
+            if (three_vol) {
+                if ((rc = e->aggr3.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
+                S3 = (int16_t *)e->aggr3.p;
+            }
             if (two_vol && do_pre) {
                 if (!e->aux) {
                     HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
@@ -840,6 +853,18 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 KCHECK();
                 if ((rc = stage_end(e, 1, e->aux))) return rc;
                 HIP_TRY(hipEventRecord(e->ev_join, e->aux));
+                if (three_vol) {
+                    if (!e->aux2) {
+                        HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
+                        HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
+                    }
+                    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
+                    if ((rc = stage_begin(e, "path_E", e->aux2))) return rc;
+                    launch_rows_grouped(g, H, GWs, +1, PATH_FIRST, C, S3, 1, wta, e->aux2);
+                    KCHECK();
+                    if ((rc = stage_end(e, 1, e->aux2))) return rc;
+                    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
+                }
             }
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
             for (int pass = 0; pass < npass && do_mid; pass++) {
@@ -892,7 +917,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     else if (GWs == 16) SGM_VERT(16);
                     else SGM_VERT(32);
 #undef SGM_VERT
-                    launch_rows_grouped(g, H, GWs, xdir, PATH_ACCUM, C, S, 1, wta, st);
+                    if (!three_vol) launch_rows_grouped(g, H, GWs, xdir, PATH_ACCUM, C, S, 1, wta, st);
                 } else if (chain) {
                     if ((rc = launch_chain(g, a, fr, pass == 0 ? SWEEP_FIRST : SWEEP_ACCUM, chain_window(g, R, nbands, 1, e->chain_wgs), st))) return rc;
                 } else if ((rc = launch_sweep(g, a, pass == 0 ? SWEEP_FIRST : (last ? SWEEP_LAST : SWEEP_ACCUM), nbands, st))) {
@@ -904,6 +929,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             if (!do_post) return SGM_OK;
             if (two_vol) {
                 HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+                if (three_vol) HIP_TRY(hipStreamWaitEvent(st, e->ev_join2, 0));
                 stage_break(e);
             }
             if (g.mode == 0 && !two_vol) {
@@ -930,15 +956,27 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             HIP_TRY(hipFuncSetAttribute((const void *)k_wta_t<POSW_, LG_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                                    \
         hipLaunchKernelGGL((k_wta_t<POSW_, LG_>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,              \
-                           (const int16_t *)nullptr);                                                                  \
+                           (const int16_t *)nullptr, (const int16_t *)nullptr);                                        \
     } while (0)
 #define SGM_WTA2(POSW_, LG_)                                                                                           \
     do {                                                                                                               \
         if (lds > 48 * 1024)                                                                                           \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_wta_t<POSW_, LG_, true>,                                       \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_wta_t<POSW_, LG_, 2>,                                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hipLaunchKernelGGL((k_wta_t<POSW_, LG_, true>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,        \
-                           (const int16_t *)S2);                                                                       \
+        hipLaunchKernelGGL((k_wta_t<POSW_, LG_, 2>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,           \
+                           (const int16_t *)S2, (const int16_t *)nullptr);                                             \
+    } while (0)
+#define SGM_WTA3(POSW_, LG_)                                                                                           \
+    hipLaunchKernelGGL((k_wta_t<POSW_, LG_, 3>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,               \
+                       (const int16_t *)S2, (const int16_t *)S3)
+#define SGM_WTA3_LG(POSW_)                      \
+    do {                                        \
+        switch (lgc) {                          \
+        case 1: SGM_WTA3(POSW_, 1); break;      \
+        case 2: SGM_WTA3(POSW_, 2); break;      \
+        case 3: SGM_WTA3(POSW_, 3); break;      \
+        default: SGM_WTA3(POSW_, -1); break;    \
+        }                                       \
     } while (0)
 #define SGM_WTA2_LG(POSW_)                      \
     do {                                        \
@@ -963,14 +1001,20 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         }                                       \
     } while (0)
                 if (two_vol) {
-                    if (g.uniq < 100) SGM_WTA2_LG(true);
+                    if (three_vol) {
+                        if (g.uniq < 100) SGM_WTA3_LG(true);
+                        else SGM_WTA3_LG(false);
+                    } else if (g.uniq < 100) SGM_WTA2_LG(true);
                     else SGM_WTA2_LG(false);
                     if (e->keep_aggr) {  // the volume a caller inspects is the whole sum
                         const int64_t n8 = (int64_t)g.rowsz * H / 8;  // rowsz = W1 * D is a multiple of 16
                         hipLaunchKernelGGL(k_add_sat, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, S, (const int16_t *)S2, n8);
+                        if (three_vol) hipLaunchKernelGGL(k_add_sat, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, S, (const int16_t *)S3, n8);
                     }
                 } else if (g.uniq < 100) SGM_WTA_LG(true);
                 else SGM_WTA_LG(false);
+#undef SGM_WTA3_LG
+#undef SGM_WTA3
 #undef SGM_WTA2_LG
 #undef SGM_WTA2
 #undef SGM_WTA_LG
@@ -1126,9 +1170,14 @@ void sgm_destroy(sgm_engine *e)
     (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->aggr2, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2, &e->pstate, &e->pstate2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
-                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom, &e->chain_ctl, &e->chain_err};
+                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom, &e->chain_ctl, &e->chain_err, &e->aggr3};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->aux2) {
+        (void)hipStreamSynchronize(e->aux2);
+        (void)hipEventDestroy(e->ev_join2);
+        (void)hipStreamDestroy(e->aux2);
+    }
     if (e->aux) {
         (void)hipStreamSynchronize(e->aux);
         (void)hipEventDestroy(e->ev_fork);

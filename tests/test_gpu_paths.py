@@ -32,14 +32,15 @@ def test_large_blocks_and_high_prefilter_caps(H, W, D, bs, cap, mode):
         assert not bad, f"schedule {schedule}: " + "\n".join(bad)
 
 
-@pytest.mark.parametrize("debug", [8, 16, 32, 128, 16 | 32, 4, 4 | 16, 512, 65536, 2, 2048])
+@pytest.mark.parametrize("debug", [8, 16, 32, 128, 16 | 32, 4, 4 | 16, 512, 65536, 2, 2048, 4096, 4096 | 16])
 @pytest.mark.parametrize("H,W,D,bs,mode", [(45, 420, 256, 7, 1), (38, 300, 64, 5, 1), (41, 200, 16, 11, 0), (29, 640, 160, 5, 0)])
 def test_debug_switches_keep_results(debug, H, W, D, bs, mode):
     """8: k_vsum_ring with 4 int16 per thread; 16: the pre-pass as three launches of the single-direction
     kernel (what frames with rowsz*H >= 2^31 take); 32: no auxiliary stream; 128: fork before the
     downward pre-pass; 4: no lane groups; 65536: MODE_SGBM's fifth path after the sweep (S +=) instead of
     beside it into its own volume; 2 / 2048: winner-take-all fused into the last path kernel / always its own pass
-    (csrc/sgm_debug.h).  Results must not change; 256 (int16 cost pipeline) is in
+    (csrc/sgm_debug.h); 4096: D <= 64, the left-to-right in-row path after the vertical kernel instead of beside it
+    into a third volume.  Results must not change; 256 (int16 cost pipeline) is in
     test_gpu_parity.py::test_both_winner_take_all_forms."""
     l, r, _ = synth.make_pair(H, W, D, 300 + debug)
     p = U.params(D, bs, 0, mode, speckleWindowSize=30, speckleRange=2)

@@ -1,20 +1,17 @@
 cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 run() {
-  echo "== $* (GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES)"
+  echo "== $*"
   timeout -k 10 300 python bench.py --workload $1 $2 $3 $4 $5 --stages --no-cpu-baseline --no-latency-mode 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print('ms/step',round(d['ms_per_step'],3),'ms/pair',round(d['ms_per_pair'],3),'pairs/s',round(d['pairs_per_s'],2))
-    elif 'chain' in l or 'sum' in l: print(l.rstrip())
+    elif 'amdgpu' not in l: print(l.rstrip())
 "
 }
-run c3c5x12
-run c4t
-run c4t32
-export GPU_MAX_HW_QUEUES=8
-run c3c5x12
-run c4t32
-export GPU_MAX_HW_QUEUES=16
-run c3c5x12
-run c4t32
+run c1
+run c1 --debug 4096
+run nb
+run nb --debug 4096
+run c1x8

@@ -80,8 +80,8 @@ def main():
             if re.search(rx, name):
                 # the in-row kernel of the small-D schedule runs inside the sweep stages; both pre-pass stages share one kernel
                 targets = [s for s in stage_ms if s.startswith("prepass")] if st == "prepass" else [st]
-                if st == "path_W" and "path_W" not in stage_ms:
-                    targets = [s for s in stage_ms if s.startswith("sweep")] or [st]
+                if st == "path_W":   # the in-row kernel: both in-row stages of the small-D schedule, else the sweep stages it runs in
+                    targets = [s for s in stage_ms if s in ("path_W", "path_E")] or [s for s in stage_ms if s.startswith("sweep")] or [st]
                 for t in targets:
                     rec = stages.setdefault(t, {"kernels": [], "bytes_per_pair": 0.0, "kernel_launches_per_pair": 0.0})
                     rec["kernels"].append(name)
