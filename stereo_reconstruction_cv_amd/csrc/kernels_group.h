@@ -29,7 +29,12 @@ template <int GW, int NP, bool PARTIAL, int MODE, bool POSW>
 __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__restrict__ C, int16_t *__restrict__ S,
                                                int keepS, uint2 *__restrict__ wta)
 {
-    constexpr int G = 64 / GW, PB = 8;
+    // Prefetch block: the loads of block b + 1 are issued PB pixels before their first use.  These kernels run one
+    // wave per SIMD (a frame has fewer rows than the GPU has SIMDs), so nothing but the prefetch distance hides memory
+    // latency: with PB = 8 the D <= 128 kernels ran at exactly "latency / 8" per pixel (4K D=16: 230 ns per pixel = 1.8 us
+    // of latency under load, against about 60 ns of instructions) -- round 3.  D > 128 (NP >= 2) is bound by its
+    // instruction stream (WTA fused: about 250 instructions per pixel) and keeps 8.
+    constexpr int G = 64 / GW, PB = NP == 1 ? 32 : 8;
     static_assert(GW == 64 || (NP == 1 && PARTIAL), "lane groups hold D <= 64: one packed register per lane");
     const int lane = threadIdx.x, gi = GW == 64 ? 0 : lane / GW, li = lane % GW;  // (GW = 64: the row must be provably uniform)
     const int W1 = g.W1, D = g.D, H = g.H;
@@ -161,7 +166,7 @@ template <int GW>
 __global__ __launch_bounds__(64) void k_prepass3_g(Geom g, int xdir, int ydir, const int16_t *__restrict__ C,
                                                    int16_t *__restrict__ bnd)
 {
-    constexpr int G = 64 / GW, NP = 1, PF = 8;
+    constexpr int G = 64 / GW, NP = 1, PF = 24;  // rows of prefetch distance (one wave per SIMD: see k_rows_g)
     constexpr int NR = 1;  // roles handled by this wave
     constexpr int OOB = (int)0xfffffff0u;
     const int lane = threadIdx.x, gi = lane / GW, li = lane % GW;

@@ -11,7 +11,8 @@ for l in sys.stdin:
 "
 }
 run c1
-run c1 --debug 4096
 run nb
-run nb --debug 4096
 run c1x8
+run c4
+run c2
+run c4t
