@@ -56,7 +56,7 @@ WORKLOADS = {
     "c1": (720, 1280, 64, 5, 0, 1, False, 1, False, "1280x720 D=64 bs=5 5-path (BASELINE configs[0])"),
     "c1x8": (720, 1280, 64, 5, 0, 8, False, 1, False, "8x 1280x720 D=64 bs=5 5-path per step on eight HIP streams"),
     "c1x16": (720, 1280, 64, 5, 0, 16, False, 1, False, "16x 1280x720 D=64 bs=5 5-path per step on sixteen HIP streams"),
-    "c1x32": (720, 1280, 64, 5, 0, 32, False, 1, False, "32x 1280x720 D=64 bs=5 5-path per step"),
+    "c1t": (720, 1280, 64, 5, 0, 32, False, 2, True, "batch of 32 1280x720 D=64 bs=5 5-path pairs per step, throughput mode"),
     "c2": (2160, 3840, 128, 7, 0, 1, False, 1, False, "3840x2160 D=128 bs=7 5-path (configs[1])"),
     "c3": (2160, 3840, 256, 7, 1, 1, False, 1, False, "3840x2160 D=256 bs=7 8-path (configs[2])"),
     "c4": (1080, 1920, 128, 7, 0, 8, False, 1, False, "8x 1920x1080 D=128 bs=7 5-path per GPU (configs[3]: 64 frames over 8 GPUs)"),
@@ -458,7 +458,7 @@ def main():
     _, W1 = eng.geometry(W)
     V = 2 * H * max(W1, 0) * D
     HW = H * W
-    chained = schedule == 2 and D > 64
+    chained = schedule == 2 and D > 32
     R = 12 if chained else min(11, max(4, -(-H // (200 if mode else 240))))   # rows per band (sweep_rows_for in sgm_engine.hip)
     if args.sweep_rows:
         R = args.sweep_rows

@@ -617,7 +617,10 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         // state; needs the 3-volume state buffer below the 4 GiB a 32-bit buffer offset reaches.
         // (At D = 64 the fused sweep is still ahead: 720p 0.35 against 0.39 ms, and 3 V of state.)
         const int GWs = (e->debug & 4) ? 64 : group_width(g, H);
-        const bool rows4 = GWs <= 32 && e->sweep_rows <= 0 &&
+        // Throughput mode (schedule 2) takes D = 48 .. 64 through the chained sweeps all the same (half the lanes idle, but
+        // 7 V of traffic per pair instead of the 22 V of the per-row state: batches of small frames are bound by HBM --
+        // 32 pairs 720p D=64: 0.42 against 0.57 ms per pair); D <= 32 keeps the small-D kernels in every mode.
+        const bool rows4 = GWs <= 32 && e->sweep_rows <= 0 && !(e->schedule == 2 && GWs == 32) &&
                            (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
         const int npass = g.mode == 1 ? 2 : 1;
         // Chained schedule (SGM_OPT_SCHEDULE 2, kernels_sweep.h: k_sweep_chain): no pre-pass; the bands of a sweep hand the

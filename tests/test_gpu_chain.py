@@ -19,7 +19,7 @@ SHAPES = [
     # H, W, D, bs, mode, rows per band
     (61, 300, 128, 5, 0, 3), (47, 420, 256, 7, 1, 2), (90, 200, 80, 3, 1, 4), (33, 1100, 512, 3, 1, 1),
     (130, 228, 128, 5, 1, 9), (58, 500, 192, 5, 0, 11), (75, 400, 256, 7, 1, 5), (29, 640, 160, 5, 0, 7),
-    (40, 700, 384, 3, 1, 3),
+    (40, 700, 384, 3, 1, 3), (70, 300, 64, 5, 0, 0), (55, 260, 48, 3, 1, 0),
 ]
 
 
@@ -49,7 +49,8 @@ def test_back_to_back_frames_on_one_engine():
 
 
 def test_small_disparity_ranges_keep_their_own_schedule():
-    """D <= 64 runs the lane-grouped kernels whatever the schedule option says."""
+    """D <= 32 runs the lane-grouped kernels whatever the schedule option says (D = 48 .. 64 is chained in throughput
+    mode: SHAPES below holds D = 64 and 48 frames with the engine's own band height)."""
     l, r, _ = synth.make_pair(60, 300, 32, 9)
     p = U.params(32, 5, 0, 1, speckleWindowSize=30, speckleRange=2)
     rep, t, h = U.compare_stages(l, r, p, schedule=2)
