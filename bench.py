@@ -676,7 +676,10 @@ def main():
             got = d_disp[i].cpu().numpy()
             nbad += int((got != full).sum())
             nver += 1
+        # the other pairs of the step repeat those images: their maps must equal their source slot's
+        ndup = sum(int(not torch.equal(d_disp[i], d_disp[i % nuniq])) for i in range(nuniq, ppg))
         out["verify"] = {"full_frame_mismatches": nbad, "pairs_verified": nver, "pixels": int(H * W * nver),
+                         "repeated_pairs": ppg - min(ppg, nuniq), "repeated_pairs_differing_from_their_source": ndup,
                          "valid_fraction": float((got >= 0).mean()), "oracle_s": time.perf_counter() - t0}
         if with_xyz:
             ref = O.reproject(O.disp_to_float(full), Q)

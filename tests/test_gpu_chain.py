@@ -120,3 +120,33 @@ def test_sharded_compute_returns_compacted_point_lists():
             n = int(counts[i])
             assert n == int(mask.sum()) and n > 0
             assert np.array_equal(pts[i, :n].cpu().numpy(), xyz[mask])
+
+
+def test_ingest_pipeline_orders_the_engine_stream_with_events():
+    """dist.IngestPipeline on the GPU with one process: batches are handed to an engine that works on a torch stream of
+    its own and returns without synchronising (hip_batch_compute(stream=..., synchronize=False)); the pipeline orders
+    transfers and kernels with events only and drain() returns every batch's results, in order."""
+    import torch
+    from stereo_reconstruction_cv_amd import dist as D_
+    H, W, D, N = 50, 420, 128, 2
+    p = U.params(D, 7, 0, 1, speckleWindowSize=30, speckleRange=2)
+    Q = synth.default_Q(W)
+    dev = torch.device("cuda", 0)
+    cs = torch.cuda.Stream(dev)
+    compute = D_.hip_batch_compute(p, Q, schedule=2, stream=cs, synchronize=False)
+    batches, wants = [], []
+    for b in range(4):
+        pairs = [synth.make_pair(H, W, D, 1300 + 10 * b + i)[:2] for i in range(N)]
+        batches.append((torch.from_numpy(np.stack([a for a, _ in pairs])), torch.from_numpy(np.stack([c for _, c in pairs]))))
+        wants.append([O.sgbm_compute(a, c, **p) for a, c in pairs])
+    pipe = D_.IngestPipeline(compute, src=0, device=dev, compute_stream=cs)
+    for l, r in batches:
+        pipe.step(l, r)
+    res = pipe.drain()
+    assert len(res) == 4
+    for b, (disp, xyz) in enumerate(res):
+        for i in range(N):
+            assert np.array_equal(disp[i].cpu().numpy(), wants[b][i]), (b, i)
+            ref = O.reproject(O.disp_to_float(wants[b][i]), Q)
+            fin = np.isfinite(ref)
+            assert np.array_equal(xyz[i].cpu().numpy()[fin], ref[fin])

@@ -17,7 +17,7 @@ for f in $O/bench_*_stages.txt; do grep -v amdgpu.ids $f > $O/t; mv $O/t $f; don
 for w in default c3c5 c1 c1x8 c1t c2 c3 c4 c5 nb c3c5x2 c3c5x3 c3c5x6 c5x12 c4t; do
     python3 -c "import json; d=json.loads(open('$O/bench_$w.json').read().strip().splitlines()[-1]); print('$w', round(d['ms_per_step'],3), 'ms/step', round(d['ms_per_pair'],3), 'ms/pair', round(d['pairs_per_s'],1), 'pairs/s', round(d['value']), 'Mdisp/s')"
 done
-python bench.py --verify --no-cpu-baseline --workload c3c5x6 > $O/bench_c3c5x6_verify.json 2> /dev/null; python3 -c "import json; d=json.loads(open('$O/bench_c3c5x6_verify.json').read().strip().splitlines()[-1]); print('verify', d.get('verify'))"
+python bench.py --verify --no-cpu-baseline > $O/bench_default_verify.json 2> /dev/null; python3 -c "import json; d=json.loads(open('$O/bench_default_verify.json').read().strip().splitlines()[-1]); print('verify', d.get('verify'))"
 python tools/host_rate.py > $O/host_rate.txt 2>&1; cat $O/host_rate.txt
 BENCH_REHEARSE=1 python bench.py --gpus 2 --workload c4 --steps 2 --warmup 1 --no-cpu-baseline > $O/rehearse_n2_c4.json 2> $O/rehearse_n2_c4.err; tail -c 600 $O/rehearse_n2_c4.json
 BENCH_REHEARSE=1 python bench.py --gpus 2 --workload c3c5x6 --steps 2 --warmup 1 --no-cpu-baseline > $O/rehearse_n2_c3c5x6.json 2> $O/rehearse_n2_c3c5x6.err; tail -c 600 $O/rehearse_n2_c3c5x6.json

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak on frames wide enough for the large-frame kernels (W1 > 1536: k_prepass3 row chunks,
-fused sweeps with a loader wave, bands up to 11 rows) -- what tests/test_gpu_fuzz.py's tiny frames do not reach.
+fused sweeps with a loader wave, bands up to 11 rows; chained sweeps with bands up to 12 rows and 1 .. 40 workgroups in
+flight) -- what tests/test_gpu_fuzz.py's tiny frames do not reach.
   gpurun -- 'python tools/soak_medium.py 40'
 Every case: all stage taps + final disparity + headroom record against the oracle; exits non-zero on a mismatch."""
 import os
@@ -36,13 +37,17 @@ for seed in range(n):
     if not t["headroom_ok"]:
         print(f"case {seed}: outside the regime, skipped")
         continue
-    h = U.run_hip_with_taps(l, r, p, schedule=1, sweep_rows=rows, prepass_rows=chunk)
-    errs = [k for k in ("C", "S", "disp_raw", "disp_median") if k in h and k in t and not np.array_equal(h[k], t[k])]
-    if not np.array_equal(h["disp"], want):
-        errs.append("disp")
-    if not U.headroom_equal(h, t):
-        errs.append("headroom")
-    print(f"case {seed}: {H}x{W} D={D} bs={bs} mode={mode} rows={rows} chunk={chunk}: {'OK' if not errs else 'MISMATCH ' + ','.join(errs)}", flush=True)
+    errs = []
+    wgs = int(rng.choice([0, 1, 3, 9, 40]))
+    for schedule in (1, 2):     # latency mode (pre-pass + sweeps) and throughput mode (chained sweeps, `wgs` workgroups in flight)
+        h = U.run_hip_with_taps(l, r, p, schedule=schedule, sweep_rows=rows if schedule == 1 else int(rng.choice([0, 4, 7, 12])),
+                                prepass_rows=chunk if schedule == 1 else 0, chain_wgs=wgs if schedule == 2 else 0)
+        errs += [f"s{schedule}:{k}" for k in ("C", "S", "disp_raw", "disp_median") if k in h and k in t and not np.array_equal(h[k], t[k])]
+        if not np.array_equal(h["disp"], want):
+            errs.append(f"s{schedule}:disp")
+        if not U.headroom_equal(h, t):
+            errs.append(f"s{schedule}:headroom")
+    print(f"case {seed}: {H}x{W} D={D} bs={bs} mode={mode} rows={rows} chunk={chunk} chain_wgs={wgs}: {'OK' if not errs else 'MISMATCH ' + ','.join(errs)}", flush=True)
     bad += bool(errs)
 print(f"{n} cases, {bad} with mismatches")
 sys.exit(1 if bad else 0)
