@@ -374,6 +374,12 @@ def hip_batch_compute(params: dict, Q=None, want_float: bool = False, schedule: 
         xyz = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev) if Qm is not None else None
         if stream is None:
             torch.cuda.current_stream(dev).synchronize()  # the engine runs on its own stream
+        else:
+            # the engine reads / writes these on `stream`, which the caching allocator does not know about: without this
+            # a tensor the caller drops right after the (asynchronous) call is handed out again while kernels still use it
+            for t in (lefts, rights, disp, dispf, xyz):
+                if t is not None:
+                    t.record_stream(stream)
         if n:
             ptrs = lambda t: [t[i].data_ptr() for i in range(n)]
             eng.pipeline_batch_device(ptrs(lefts), ptrs(rights), H, W, W, Qm, ptrs(disp),
