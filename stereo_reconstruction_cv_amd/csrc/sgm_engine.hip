@@ -861,12 +861,15 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                         HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
                         HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
                     }
-                    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-                    if ((rc = stage_begin(e, "path_E", e->aux2))) return rc;
-                    launch_rows_grouped(g, H, GWs, +1, PATH_FIRST, C, S3, 1, wta, e->aux2);
+                    // debug 8192: both in-row paths one after the other on the first auxiliary stream (A/B: two instead of
+                    // three latency-bound kernels side by side)
+                    hipStream_t s2 = (e->debug & SGM_DBG_IN_ROW_PATHS_ONE_STREAM) ? e->aux : e->aux2;
+                    if (s2 != e->aux) HIP_TRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
+                    if ((rc = stage_begin(e, "path_E", s2))) return rc;
+                    launch_rows_grouped(g, H, GWs, +1, PATH_FIRST, C, S3, 1, wta, s2);
                     KCHECK();
-                    if ((rc = stage_end(e, 1, e->aux2))) return rc;
-                    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
+                    if ((rc = stage_end(e, 1, s2))) return rc;
+                    HIP_TRY(hipEventRecord(e->ev_join2, s2));
                 }
             }
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;

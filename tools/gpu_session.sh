@@ -1,3 +1,18 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-timeout -k 10 900 python tools/soak_medium.py 40 > gpurun_out/soak_medium_r03.log 2>&1; tail -3 gpurun_out/soak_medium_r03.log
+run() {
+  echo "== $*"
+  timeout -k 10 300 python bench.py --workload $1 $2 $3 $4 $5 $6 $7 $8 --stages --no-cpu-baseline --no-latency-mode 2>&1 | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('ms/step',round(d['ms_per_step'],3),'ms/pair',round(d['ms_per_pair'],3),'pairs/s',round(d['pairs_per_s'],2))
+    elif 'path' in l or 'prepass' in l or 'sweep' in l or 'sum' in l: print(l.rstrip())
+"
+}
+run nb
+run nb --debug 8192
+run nb --debug 4096
+run c1
+run c1 --debug 8192
+run nb
+run nb --debug 8192
