@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
+timeout -k 10 300 python -m pytest tests/test_gpu_paths.py tests/test_gpu_parity.py -x -q 2>&1 | tail -3
 run() {
   echo "== $*"
   timeout -k 10 300 python bench.py --workload $1 $2 $3 $4 $5 $6 $7 $8 --stages --no-cpu-baseline --no-latency-mode 2>&1 | python -c "
@@ -10,9 +11,8 @@ for l in sys.stdin:
 "
 }
 run nb
-run nb --debug 8192
-run nb --debug 4096
+run nb --debug 16384
 run c1
-run c1 --debug 8192
+run c1 --debug 16384
 run nb
-run nb --debug 8192
+run c1x8
