@@ -51,10 +51,6 @@ __global__ __launch_bounds__(64) void k_rows_g(Geom g, int rx, const int16_t *__
     const __amdgpu_buffer_rsrc_t Cv = uniform_rsrc(C, rowoff, (int)span), Sv = uniform_rsrc(S, rowoff, (int)span);
     const __amdgpu_buffer_rsrc_t Sst = Sv;
     const bool stores_S = MODE != PATH_LAST || keepS;
-    // keepS bit 8: this launch is the long pole of a frame whose other kernels run beside it on other streams (the
-    // in-row paths of the small-D schedule beside the per-row pre-pass): its few, long-running waves win the issue
-    // arbitration on the SIMDs they share (s_setprio: priority outranks age)
-    if (keepS & 8) __builtin_amdgcn_s_setprio(3);
     const int voff = active ? (GW == 64 ? 0 : y * row_bytes) + li * NP * 4 : SGM_OOB;
     const int pxb = D * 2;
     const uint32_t P1s = splat16((uint32_t)g.P1), P2s = splat16((uint32_t)g.P2);

@@ -21,8 +21,6 @@ enum {
     SGM_DBG_PREPASS_ONE_CHUNK = 512,     /* pre-pass in one chunk with the plain line-per-block layout */
     SGM_DBG_WTA_SEPARATE = 2048,         /* winner-take-all always as its own pass */
     SGM_DBG_IN_ROW_ON_MAIN_STREAM = 4096, /* D <= 64, MODE_SGBM: the left-to-right in-row path after the vertical kernel (S +=) instead of beside it */
-    SGM_DBG_IN_ROW_PATHS_ONE_STREAM = 8192, /* D <= 64, MODE_SGBM: both in-row paths on ONE auxiliary stream, one after the other */
-    SGM_DBG_NO_WAVE_PRIORITY = 16384,    /* D <= 64, MODE_SGBM: the in-row paths beside the pre-pass without raised wave priority */
     SGM_DBG_FIFTH_PATH_AFTER_SWEEP = 65536 /* MODE_SGBM, D <= 128: the fifth path after the sweep (S +=) instead of beside it */
 };
 

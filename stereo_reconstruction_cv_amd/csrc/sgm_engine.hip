@@ -852,7 +852,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 HIP_TRY(hipEventRecord(e->ev_fork, st));
                 HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
                 if ((rc = stage_begin(e, "path_W", e->aux))) return rc;
-                launch_rows_grouped(g, H, group_width(g, H), -1, PATH_FIRST, C, S2, (three_vol && !(e->debug & 16384)) ? 9 : 1, wta, e->aux);
+                launch_rows_grouped(g, H, group_width(g, H), -1, PATH_FIRST, C, S2, 1, wta, e->aux);
                 KCHECK();
                 if ((rc = stage_end(e, 1, e->aux))) return rc;
                 HIP_TRY(hipEventRecord(e->ev_join, e->aux));
@@ -861,15 +861,12 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                         HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
                         HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
                     }
-                    // debug 8192: both in-row paths one after the other on the first auxiliary stream (A/B: two instead of
-                    // three latency-bound kernels side by side)
-                    hipStream_t s2 = (e->debug & SGM_DBG_IN_ROW_PATHS_ONE_STREAM) ? e->aux : e->aux2;
-                    if (s2 != e->aux) HIP_TRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
-                    if ((rc = stage_begin(e, "path_E", s2))) return rc;
-                    launch_rows_grouped(g, H, GWs, +1, PATH_FIRST, C, S3, (e->debug & 16384) ? 1 : 9, wta, s2);
+                    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
+                    if ((rc = stage_begin(e, "path_E", e->aux2))) return rc;
+                    launch_rows_grouped(g, H, GWs, +1, PATH_FIRST, C, S3, 1, wta, e->aux2);
                     KCHECK();
-                    if ((rc = stage_end(e, 1, s2))) return rc;
-                    HIP_TRY(hipEventRecord(e->ev_join2, s2));
+                    if ((rc = stage_end(e, 1, e->aux2))) return rc;
+                    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
                 }
             }
             if (overlap && fork_early && (rc = fork_prepass_up())) return rc;
