@@ -150,3 +150,43 @@ def test_ingest_pipeline_orders_the_engine_stream_with_events():
             ref = O.reproject(O.disp_to_float(wants[b][i]), Q)
             fin = np.isfinite(ref)
             assert np.array_equal(xyz[i].cpu().numpy()[fin], ref[fin])
+
+
+def test_chained_batch_beside_other_work_on_the_gpu():
+    """The hand-off between bands (write-through record + progress word, polled by the band below) under UNEVEN load:
+    while a chained batch of six medium frames runs on one engine, a second engine keeps the GPU busy with
+    latency-mode frames on a stream of its own (pre-pass, sweeps, cost kernels competing for CUs, L2 and HBM), twice
+    over.  Workgroups of the chained launch then start late, out of order and on whatever CUs are free -- the ticket
+    order makes that harmless -- and every map of both engines must still equal the oracle's."""
+    import torch
+    H, W, D = 260, 1500, 128
+    p = U.params(D, 7, 0, 1, speckleWindowSize=30, speckleRange=2)
+    pairs = [synth.make_pair(H, W, D, 2100 + i)[:2] for i in range(3)]
+    wants = [O.sgbm_compute(a, b, **p) for a, b in pairs]
+    dev = torch.device("cuda", 0)
+    n = 6
+    dl = [torch.from_numpy(pairs[i % 3][0]).to(dev) for i in range(n)]
+    dr = [torch.from_numpy(pairs[i % 3][1]).to(dev) for i in range(n)]
+    dd = [torch.empty((H, W), dtype=torch.int16, device=dev) for _ in range(n)]
+    other = [torch.empty((H, W), dtype=torch.int16, device=dev) for _ in range(8)]
+    torch.cuda.synchronize()
+    a = Engine(p)
+    a.set_option(_lib.SGM_OPT_SCHEDULE, 2)
+    b = Engine(p)                      # latency mode, its own stream
+    ptr = lambda ts: [t.data_ptr() for t in ts]
+    for rep in range(2):
+        for t in dd + other:
+            t.fill_(-9)
+        torch.cuda.synchronize()
+        for k in range(4):
+            b.compute_device(dl[k % 3].data_ptr(), dr[k % 3].data_ptr(), H, W, W, other[k].data_ptr())
+        a.pipeline_batch_device(ptr(dl), ptr(dr), H, W, W, None, ptr(dd))
+        for k in range(4, 8):
+            b.compute_device(dl[k % 3].data_ptr(), dr[k % 3].data_ptr(), H, W, W, other[k].data_ptr())
+        a.synchronize()
+        b.synchronize()
+        for i in range(n):
+            got = dd[i].cpu().numpy()
+            assert np.array_equal(got, wants[i % 3]), (rep, i, int((got != wants[i % 3]).sum()))
+        for k in range(8):
+            assert np.array_equal(other[k].cpu().numpy(), wants[k % 3]), (rep, k)
