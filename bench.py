@@ -56,7 +56,7 @@ WORKLOADS = {
     "c1": (720, 1280, 64, 5, 0, 1, False, 1, False, "1280x720 D=64 bs=5 5-path (BASELINE configs[0])"),
     "c1x8": (720, 1280, 64, 5, 0, 8, False, 1, False, "8x 1280x720 D=64 bs=5 5-path per step on eight HIP streams"),
     "c1x16": (720, 1280, 64, 5, 0, 16, False, 1, False, "16x 1280x720 D=64 bs=5 5-path per step on sixteen HIP streams"),
-    "c1t": (720, 1280, 64, 5, 0, 32, False, 2, True, "batch of 32 1280x720 D=64 bs=5 5-path pairs per step, throughput mode"),
+    "c1t": (720, 1280, 64, 5, 0, 64, False, 2, True, "batch of 64 1280x720 D=64 bs=5 5-path pairs per step, throughput mode"),
     "c2": (2160, 3840, 128, 7, 0, 1, False, 1, False, "3840x2160 D=128 bs=7 5-path (configs[1])"),
     "c3": (2160, 3840, 256, 7, 1, 1, False, 1, False, "3840x2160 D=256 bs=7 8-path (configs[2])"),
     "c4": (1080, 1920, 128, 7, 0, 8, False, 1, False, "8x 1920x1080 D=128 bs=7 5-path per GPU (configs[3]: 64 frames over 8 GPUs)"),
@@ -70,8 +70,8 @@ WORKLOADS = {
                 "batch of twelve 3840x2160 D=256 bs=7 MODE_HH 8-path pairs per step (+ LR + subpixel + median + speckle + "
                 "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch"),
     "c5x12": (2160, 3840, 256, 7, 0, 12, True, 2, True, "batch of twelve 4K D=256 5-path pairs per step + reproject, throughput mode"),
-    "c4t": (1080, 1920, 128, 7, 0, 16, False, 2, True, "batch of sixteen 1920x1080 D=128 5-path pairs per step, throughput mode"),
-    "c4t32": (1080, 1920, 128, 7, 0, 32, False, 2, True, "batch of 32 1920x1080 D=128 5-path pairs per step, throughput mode"),
+    "c4t": (1080, 1920, 128, 7, 0, 32, False, 2, True, "batch of 32 1920x1080 D=128 5-path pairs per step, throughput mode"),
+    "c4t64": (1080, 1920, 128, 7, 0, 64, False, 2, True, "batch of 64 1920x1080 D=128 5-path pairs per step (all of BASELINE configs[3] on one GPU), throughput mode"),
     "nb": (2160, 3840, 16, 11, 0, 1, True, 1, False, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
     "tiny": (96, 480, 64, 7, 1, 2, True, 1, False, "96x480 D=64 MODE_HH x2 (launcher rehearsal only, not a BASELINE config)"),
     "tinyt": (96, 480, 128, 7, 1, 3, True, 2, True, "96x480 D=128 MODE_HH x3, throughput mode (launcher rehearsal only)"),

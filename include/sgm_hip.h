@@ -185,7 +185,7 @@ int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, 
                         void *d_disp_f32, void *d_xyz_f32);
 /* The driver cell over N resident pairs (BASELINE config 4: a batch of pairs per GPU; main.ipynb:780-797 once per pair),
  * throughput mode: arrays of N device pointers (d_disp_f32 / d_xyz_f32 may be NULL).  With SGM_OPT_SCHEDULE = 2 the
- * pairs share ONE chained sweep launch per pass (groups of up to 32 pairs on internal engines: about 13 GB of device
+ * pairs share ONE chained sweep launch per pass (groups of up to 64 pairs on internal engines: about 13 GB of device
  * memory per 4K D=256 pair of a group); otherwise pair after pair.  Results equal N calls of sgm_pipeline_device.
  * Asynchronous: sgm_synchronize(e) waits for all of it. */
 int sgm_pipeline_batch_device(sgm_engine *e, int N, const void *const *d_left, const void *const *d_right, int H, int W,

@@ -46,7 +46,7 @@ struct SweepArgs {
 
 // Frames of one chained launch (sgm_pipeline_batch_device: several pairs per launch, so that the GPU is full although
 // one frame's chain keeps only T / LAG workgroups busy).  Tickets go round the frames: ticket t = band t / nf of frame t % nf.
-constexpr int CHAIN_MAX_FRAMES = 32;
+constexpr int CHAIN_MAX_FRAMES = 64;   // (the four pointer arrays of ChainFrames: 2 KB of the 4 KB a kernel's arguments may take)
 struct ChainFrames {
     int nf;
     const int16_t *C[CHAIN_MAX_FRAMES];
