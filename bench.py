@@ -82,7 +82,7 @@ DEFAULT_WORKLOAD = "c3c5x12"
 STAGE_KERNEL = {
     "chain_dn": "k_sweep_chain<NP,*,SWEEP_FIRST>", "chain_up": "k_sweep_chain<NP,*,SWEEP_ACCUM>",
     "sweep_dn": "k_sweep<NP,*,SWEEP_FIRST>", "sweep_up": "k_sweep<NP,*,SWEEP_ACCUM>", "sweep_up_wta": "k_sweep<NP,*,SWEEP_LAST>",
-    "prepass_dn": "k_prepass3<NP,*>", "prepass_up": "k_prepass3<NP,*>", "path_W_wta": "k_rows_g<64,NP,*,PATH_LAST>",
+    "prepass_dn": "k_prepass3<NP,*>", "prepass_up": "k_prepass3<NP,*>", "paths5": "k_paths5_g<GW,*>", "path_W_wta": "k_rows_g<64,NP,*,PATH_LAST>",
     "path_W": "k_rows_g<GW,NP,*,PATH_FIRST|ACCUM>", "path_E": "k_rows_g<GW,NP,*,PATH_FIRST|ACCUM>", "wta": "k_wta_t", "cost_pix": "k_pix<NP>", "cost_box": "k_box_u8<R,NP>",
     "cost_hsum": "k_hsum<NP,RS>", "cost_vsum": "k_vsum_ring<SH2,NW>", "features": "k_features", "select_lr": "k_select",
     "median3": "k_median3", "speckle": "k_ccl_*", "to_float": "k_disp_to_float", "reproject": "k_reproject",
@@ -131,8 +131,9 @@ def model_traffic(stage: str, V: int, R: int, HW: int, mode: int, D: int) -> int
         "chain_dn": 2 * V + 2 * bnd, "chain_up": 3 * V + 2 * bnd,
         "sweep_dn": 2 * V + bnd, "sweep_up": 3 * V + bnd, "sweep_up_wta": 2 * V + bnd,
         "prepass_dn": 3 * V + bnd, "prepass_up": 3 * V + bnd,
+        "paths5": 6 * V,         # D <= 64, MODE_SGBM, one launch: C read once (five directions: L2), one volume written per direction
         "path_W_wta": 2 * V, "path_W": 2 * V if two_vol else 3 * V, "path_E": 2 * V,
-        "wta": ((3 * V if D <= 64 else 2 * V) if two_vol else V) + 8 * HW,
+        "wta": ((5 * V if D <= 64 else 2 * V) if two_vol else V) + 8 * HW,
         "cost_pix": V // 2 + 14 * HW, "cost_box": V // 2 + V, "cost_hsum": V + 14 * HW, "cost_vsum": 2 * V,
     }.get(stage)
 

@@ -40,20 +40,43 @@ struct ShiftRegs {
 
 // Lane groups (GW < 64, several pixels per wave): first / last say whether this lane is the first /
 // last of its group; those lanes must see the sentinel, not the neighbouring group's value.
+// Kept as per-lane WORDS, {MAX_COST, MAX_COST} on the edge lane and 0 elsewhere: path states are packed pairs of values in
+// [0, 0x7fff] (the int16 regime; wave_min4_splat), so the unsigned 32-bit maximum of a shifted-in state and the edge
+// word is the sentinel on an edge lane and the state elsewhere -- and that maximum takes the DPP shift as its
+// operand: ONE v_max_u32_dpp per shift instead of v_mov_b32_dpp + v_cndmask_b32.  (bound_ctrl: lanes 0 / 63,
+// which have no source lane, read 0 and are edge lanes of their groups.)  The small-D kernels are bound by the
+// instruction stream of a single wave: every instruction per step counts there.
 struct GroupEdge {
-    bool first = false, last = false;
+    uint32_t first = 0, last = 0;
+    __device__ __forceinline__ void set(int li, int GW)
+    {
+        first = li == 0 ? SGM_SENT : 0u;
+        last = li == GW - 1 ? SGM_SENT : 0u;
+    }
 };
+// the value a lane group's pixel sees one lane down / up, edges holding the sentinel
+template <int GW> __device__ __forceinline__ uint32_t group_from_lower(uint32_t v, const GroupEdge &ge)
+{
+    return max(dpp_view<DPP_WAVE_SHR1>(v), ge.first);
+}
+template <int GW> __device__ __forceinline__ uint32_t group_from_upper(uint32_t v, const GroupEdge &ge)
+{
+    return max(dpp_view<DPP_WAVE_SHL1>(v), ge.last);
+}
 template <int NP, bool PARTIAL, int GW = 64>
 __device__ __forceinline__ void path_elem(const Pack<NP> &Cp, const Pack<NP> &Lq, uint32_t P1s, uint32_t P2s,
                                           bool active, Pack<NP> &Ln, uint32_t &rmin, ShiftRegs &sr,
                                           GroupEdge ge = GroupEdge())
 {
-    sr.up = from_lower_lane(Lq.r[NP - 1], sr.up);
-    sr.dn = from_upper_lane(Lq.r[0], sr.dn);
-    uint32_t up = sr.up, dn = sr.dn;
-    if (GW < 64) {
-        up = ge.first ? SGM_SENT : up;
-        dn = ge.last ? SGM_SENT : dn;
+    uint32_t up, dn;
+    if constexpr (GW < 64) {
+        up = group_from_lower<GW>(Lq.r[NP - 1], ge);
+        dn = group_from_upper<GW>(Lq.r[0], ge);
+    } else {
+        sr.up = from_lower_lane(Lq.r[NP - 1], sr.up);
+        sr.dn = from_upper_lane(Lq.r[0], sr.dn);
+        up = sr.up;
+        dn = sr.dn;
     }
     rmin = SGM_SENT;
 #pragma unroll
@@ -82,12 +105,15 @@ template <int NP, bool PARTIAL, int GW = 64>
 __device__ __forceinline__ void path_inner_min(const Pack<NP> &U, uint32_t P1s, Pack<NP> &t, ShiftRegs &sr,
                                                GroupEdge ge = GroupEdge())
 {
-    sr.up = from_lower_lane(U.r[NP - 1], sr.up);
-    sr.dn = from_upper_lane(U.r[0], sr.dn);
-    uint32_t up = sr.up, dn = sr.dn;
-    if (GW < 64) {
-        up = ge.first ? SGM_SENT : up;
-        dn = ge.last ? SGM_SENT : dn;
+    uint32_t up, dn;
+    if constexpr (GW < 64) {
+        up = group_from_lower<GW>(U.r[NP - 1], ge);
+        dn = group_from_upper<GW>(U.r[0], ge);
+    } else {
+        sr.up = from_lower_lane(U.r[NP - 1], sr.up);
+        sr.dn = from_upper_lane(U.r[0], sr.dn);
+        up = sr.up;
+        dn = sr.dn;
     }
 #pragma unroll
     for (int i = 0; i < NP; i++) {

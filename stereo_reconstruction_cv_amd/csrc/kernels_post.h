@@ -99,20 +99,23 @@ __global__ __launch_bounds__(256) void k_add_sat(int16_t *__restrict__ S, const 
 // (multiple of 16), plain staging.
 // NV: the costs are the saturating sum of NV volumes.  2: S + S2 (MODE_SGBM with D <= 128: the fifth path runs
 // beside the sweep into a volume of its own); 3: S + S2 + S3 (D <= 64: both in-row paths run beside the per-row
-// pre-pass and the element-wise vertical kernel, each into a volume of its own).  Every path cost is >= 0 and the
+// pre-pass and the element-wise vertical kernel, each into a volume of its own); 5: the five directions of MODE_SGBM each
+// in a volume of its own (D <= 64: k_lines3_g + the two in-row paths).  Every path cost is >= 0 and the
 // sum saturates, so the order of the additions does not matter -- kernels_path.h.
 template <bool POSW, int LG, int NV = 1>
 __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict__ S, uint2 *__restrict__ wta, int64_t npix,
-                                              const int16_t *__restrict__ S2 = nullptr, const int16_t *__restrict__ S3 = nullptr)
+                                              const int16_t *__restrict__ S2 = nullptr, const int16_t *__restrict__ S3 = nullptr,
+                                              const int16_t *__restrict__ S4 = nullptr, const int16_t *__restrict__ S5 = nullptr)
 {
-    constexpr bool TWO = NV >= 2, THREE = NV >= 3;
+    constexpr bool TWO = NV >= 2, THREE = NV >= 3, FIVE = NV >= 5;
+    static_assert(NV == 1 || NV == 2 || NV == 3 || NV == 5, "volumes: 1, 2, 3 or 5");
     extern __shared__ __attribute__((aligned(16))) uint8_t rows[];
     const int lane = threadIdx.x, D = LG >= 0 ? (8 << LG) : g.D, W1 = g.W1;
     const int stride = wta_t_stride(D);
     const int cpr = D * 2 / 16;  // 16-byte chunks per pixel row; a lane moves cpr chunks per block
     const int64_t nblocks = (npix + 63) / 64;
     constexpr int PF = LG < 0 ? 8 : (LG >= 5 ? 32 : (1 << LG));  // chunks per lane held in registers
-    uint4 v[PF], v2[TWO ? PF : 1], v3[THREE ? PF : 1];
+    uint4 v[PF], v2[TWO ? PF : 1], v3[THREE ? PF : 1], v4[FIVE ? PF : 1], v5[FIVE ? PF : 1];
     // chunk c = lane + 64 k of the block's contiguous 64 * D * 2 bytes: loads with a clamped index
     // (no branch between them), committed to the padded LDS rows afterwards
     auto issue = [&](int64_t blk, int k0) {
@@ -131,6 +134,14 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
 #pragma unroll
             for (int u = 0; u < PF; u++) v3[u] = src3[min(lane + 64 * (k0 + u), total - 1)];
         }
+        if constexpr (FIVE) {
+            const uint4 *src4 = reinterpret_cast<const uint4 *>(S4 + blk * 64 * D);
+            const uint4 *src5 = reinterpret_cast<const uint4 *>(S5 + blk * 64 * D);
+#pragma unroll
+            for (int u = 0; u < PF; u++) v4[u] = src4[min(lane + 64 * (k0 + u), total - 1)];
+#pragma unroll
+            for (int u = 0; u < PF; u++) v5[u] = src5[min(lane + 64 * (k0 + u), total - 1)];
+        }
     };
     auto summed = [&](int u) {  // chunk u of the cost rows: S, or sat(S + S2)
         uint4 r = v[u];
@@ -145,6 +156,12 @@ __global__ __launch_bounds__(64) void k_wta_t(Geom g, const int16_t *__restrict_
             r.y = pk_adds_s(r.y, v3[u].y);
             r.z = pk_adds_s(r.z, v3[u].z);
             r.w = pk_adds_s(r.w, v3[u].w);
+        }
+        if constexpr (FIVE) {
+            r.x = pk_adds_s(pk_adds_s(r.x, v4[u].x), v5[u].x);
+            r.y = pk_adds_s(pk_adds_s(r.y, v4[u].y), v5[u].y);
+            r.z = pk_adds_s(pk_adds_s(r.z, v4[u].z), v5[u].z);
+            r.w = pk_adds_s(pk_adds_s(r.w, v4[u].w), v5[u].w);
         }
         return r;
     };

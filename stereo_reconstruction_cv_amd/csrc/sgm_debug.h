@@ -20,6 +20,7 @@ enum {
     SGM_DBG_INT16_COST = 256,            /* int16 cost pipeline (k_hsum + k_vsum_ring) instead of the byte one */
     SGM_DBG_PREPASS_ONE_CHUNK = 512,     /* pre-pass in one chunk with the plain line-per-block layout */
     SGM_DBG_WTA_SEPARATE = 2048,         /* winner-take-all always as its own pass */
+    SGM_DBG_SMALL_D_RECORD = 8192,       /* D <= 64, MODE_SGBM: per-row record + element-wise vertical kernel (k_prepass3_g + k_vert3_g) instead of k_lines3_g's volumes */
     SGM_DBG_IN_ROW_ON_MAIN_STREAM = 4096, /* D <= 64, MODE_SGBM: the left-to-right in-row path after the vertical kernel (S +=) instead of beside it */
     SGM_DBG_FIFTH_PATH_AFTER_SWEEP = 65536 /* MODE_SGBM, D <= 128: the fifth path after the sweep (S +=) instead of beside it */
 };

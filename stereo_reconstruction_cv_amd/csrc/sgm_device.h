@@ -289,11 +289,9 @@ template <int GW> __device__ __forceinline__ uint32_t group_min_splat(uint32_t r
         x = min(x, dpp_view<DPP_QUAD_2301>(x));
         x = min(x, dpp_view<DPP_ROW_HALF_MIRROR>(x));  // 8 lanes done
         if constexpr (GW >= 16) x = min(x, dpp_view<DPP_ROW_MIRROR>(x));
-        if constexpr (GW == 32) {
-            x = min(x, dpp_view<DPP_ROW_BCAST15, 0xa>(x));  // lanes 31 / 63: minimum of rows 0-1 / 2-3
-            const uint32_t a = __builtin_amdgcn_readlane(x, 31), b = __builtin_amdgcn_readlane(x, 63);
-            x = lane_id() < 32 ? a : b;
-        }
+        // two rows per group: every lane holds its row's minimum; v_permlane16_swap pairs row 0 with 1 and 2 with 3
+        // (copy + swap + minimum instead of row_bcast + minimum + two v_readlane + two moves + a select)
+        if constexpr (GW == 32) x = fold16_pair(x, x);
         return x;
     }
 }

@@ -135,6 +135,7 @@ struct sgm_engine {
     DevBuf hsum, cost, aggr;            // int16 [H][W1][D] volumes
     DevBuf aggr2;                       // MODE_SGBM, D <= 128: the fifth path's own volume (added to S by the winner-take-all)
     DevBuf aggr3;                       // MODE_SGBM, D <= 64: the other in-row path's own volume
+    DevBuf aggr4, aggr5;                // MODE_SGBM, D <= 64: the volumes of the vertical and the second diagonal direction (k_paths5_g)
     DevBuf wta;                         // uint2 [H][W]
     DevBuf bndL, bndL2;                 // band-boundary state of the sweep pre-pass (down / up)
     DevBuf pstate, pstate2;             // line state between the row chunks of the pre-pass (ping-pong, down / up)
@@ -331,9 +332,10 @@ static void launch_rows_g(const Geom &g, int H, int rx, int mode, const int16_t 
 static void launch_rows_grouped(const Geom &g, int H, int GW, int rx, int mode, const int16_t *C, int16_t *S, int keepS, uint2 *wta, hipStream_t st)
 {
     const bool partial = g.D != 128 * g.NP;
-    if (GW == 8) launch_rows_g<8, 1, true>(g, H, rx, mode, C, S, keepS, wta, st);
-    else if (GW == 16) launch_rows_g<16, 1, true>(g, H, rx, mode, C, S, keepS, wta, st);
-    else if (GW == 32) launch_rows_g<32, 1, true>(g, H, rx, mode, C, S, keepS, wta, st);
+    // lane groups: PARTIAL = the group is not full (D = 48 in groups of 32; D = 16, 32, 64 fill theirs)
+    if (GW == 8) launch_rows_g<8, 1, false>(g, H, rx, mode, C, S, keepS, wta, st);
+    else if (GW == 16) launch_rows_g<16, 1, false>(g, H, rx, mode, C, S, keepS, wta, st);
+    else if (GW == 32) { if (g.D < 64) launch_rows_g<32, 1, true>(g, H, rx, mode, C, S, keepS, wta, st); else launch_rows_g<32, 1, false>(g, H, rx, mode, C, S, keepS, wta, st); }
     else if (g.NP == 1) { if (partial) launch_rows_g<64, 1, true>(g, H, rx, mode, C, S, keepS, wta, st); else launch_rows_g<64, 1, false>(g, H, rx, mode, C, S, keepS, wta, st); }
     else if (g.NP == 2) { if (partial) launch_rows_g<64, 2, true>(g, H, rx, mode, C, S, keepS, wta, st); else launch_rows_g<64, 2, false>(g, H, rx, mode, C, S, keepS, wta, st); }
     else { if (partial) launch_rows_g<64, 4, true>(g, H, rx, mode, C, S, keepS, wta, st); else launch_rows_g<64, 4, false>(g, H, rx, mode, C, S, keepS, wta, st); }
@@ -711,8 +713,49 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             if ((rc = stage_end(e, 1))) return rc;
         } else {
             // -- fused schedule: per pass a read-only boundary pre-pass (3 line scans) + one sweep
-            const size_t bnd_bytes = (size_t)nbands * g.W1 * 3 * g.D * 2;
-            if (nbands > 1) {
+            // Winner-take-all: a separate pass over S (k_wta_t, one lane per pixel) after the second sweep
+            // of MODE_HH and after the in-row path of MODE_SGBM for D <= 128; fused into the in-row path
+            // kernel for MODE_SGBM with D > 128 (there the separate form costs a third volume of traffic:
+            // 4K D=256 2.49 ms fused against 2.56 + 0.73; D=128: 2.01 against 1.42 + 0.43, 1080p 0.79 against
+            // 0.44 + 0.10).  debug 2 forces the fused form everywhere, debug 2048 the separate one (A/B, cross-check).
+            const bool fused_wta = !(e->debug & 2048) && (((e->debug & 2) != 0 && !rows4) ||
+                                                          (g.mode == 0 && ((e->debug & 4) || g.D > 128)));
+            // MODE_SGBM with the separate winner-take-all (D <= 128): the fifth path (in-row, right to left) needs
+            // nothing but C, so it runs on the auxiliary stream from here on, as a FIRST pass into a volume of its
+            // own (2 V of traffic instead of the 3 V of "S +="), beside the pre-pass and the sweep -- which at these
+            // D are bound by instruction issue, not by HBM; k_wta_t adds the two volumes while it stages them.
+            // debug 65536: the fifth path after the sweep, accumulating into S (A/B).
+            const bool two_vol = g.mode == 0 && !fused_wta && g.D <= 128 && !(e->debug & 4) && !(e->debug & 65536);
+            int16_t *S2 = nullptr;
+            if (two_vol) {
+                if ((rc = e->aggr2.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
+                S2 = (int16_t *)e->aggr2.p;
+            }
+            // D <= 64 (small-D schedule): the OTHER in-row path (left to right) needs nothing but C either.  It used to follow
+            // the element-wise vertical kernel as "S +=" on the main stream -- a chain of W1 dependent steps on the
+            // critical path of a latency-bound frame; now it runs as a FIRST pass into a third volume on a stream of its
+            // own, beside the per-row pre-pass and k_vert3_g, and the winner-take-all adds three volumes.
+            const bool three_vol = two_vol && rows4 && !(e->debug & SGM_DBG_IN_ROW_ON_MAIN_STREAM);
+            int16_t *S3 = nullptr;
+            if (three_vol) {
+                if ((rc = e->aggr3.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
+                S3 = (int16_t *)e->aggr3.p;
+            }
+            // ... and so do the three directions that come from the row above: the walk along their lines (the "pre-pass" of
+            // the small-D schedule) forms L_r(p, .) on its way, so each role writes it to a volume of its own and the
+            // winner-take-all adds five volumes: no per-row record (3 V written, 3 V read), no element-wise kernel behind
+            // the walk -- and all five directions are ONE launch (k_paths5_g: why, see there).  debug 8192: the record form
+            // with the in-row paths on streams of their own (A/B; MODE_HH keeps it).
+            const bool five_vol = three_vol && !(e->debug & SGM_DBG_SMALL_D_RECORD);
+            int16_t *S4 = nullptr, *S5 = nullptr;
+            if (five_vol) {
+                if ((rc = e->aggr4.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
+                if ((rc = e->aggr5.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
+                S4 = (int16_t *)e->aggr4.p;
+                S5 = (int16_t *)e->aggr5.p;
+            }
+            const size_t bnd_bytes = five_vol ? 0 : (size_t)nbands * g.W1 * 3 * g.D * 2;
+            if (nbands > 1 && !five_vol) {
                 if ((rc = e->bndL.ensure(bnd_bytes))) return rc;
                 if (!chain) {
                     if (npass == 2 && (rc = e->bndL2.ensure(bnd_bytes))) return rc;
@@ -765,9 +808,10 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     // one role per wave (grid.y = 3): these frames have too few lines to fill the SIMDs with
                     // three-role waves (4K D=16: 478)
                     dim3 grid((g.W1 + 64 / GWs - 1) / (64 / GWs), 3), block(64);
-                    if (GWs == 8) hipLaunchKernelGGL((k_prepass3_g<8>), grid, block, 0, on, g, xdir, ydir, C, bl);
-                    else if (GWs == 16) hipLaunchKernelGGL((k_prepass3_g<16>), grid, block, 0, on, g, xdir, ydir, C, bl);
-                    else hipLaunchKernelGGL((k_prepass3_g<32>), grid, block, 0, on, g, xdir, ydir, C, bl);
+                    if (GWs == 8) hipLaunchKernelGGL((k_prepass3_g<8, false>), grid, block, 0, on, g, xdir, ydir, C, bl);
+                    else if (GWs == 16) hipLaunchKernelGGL((k_prepass3_g<16, false>), grid, block, 0, on, g, xdir, ydir, C, bl);
+                    else if (g.D < 64) hipLaunchKernelGGL((k_prepass3_g<32, true>), grid, block, 0, on, g, xdir, ydir, C, bl);
+                    else hipLaunchKernelGGL((k_prepass3_g<32, false>), grid, block, 0, on, g, xdir, ydir, C, bl);
                     return 1;
                 }
                 if (fused_prepass) {
@@ -815,35 +859,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             // debug bit 64+128: fork right after the cost stage (both pre-passes side by side) instead
             // of after the downward pre-pass (upward pre-pass beside the downward sweep)
             const bool fork_early = (e->debug & 128) != 0;
-            // Winner-take-all: a separate pass over S (k_wta_t, one lane per pixel) after the second sweep
-            // of MODE_HH and after the in-row path of MODE_SGBM for D <= 128; fused into the in-row path
-            // kernel for MODE_SGBM with D > 128 (there the separate form costs a third volume of traffic:
-            // 4K D=256 2.49 ms fused against 2.56 + 0.73; D=128: 2.01 against 1.42 + 0.43, 1080p 0.79 against
-            // 0.44 + 0.10).  debug 2 forces the fused form everywhere, debug 2048 the separate one (A/B, cross-check).
-            const bool fused_wta = !(e->debug & 2048) && (((e->debug & 2) != 0 && !rows4) ||
-                                                          (g.mode == 0 && ((e->debug & 4) || g.D > 128)));
-            // MODE_SGBM with the separate winner-take-all (D <= 128): the fifth path (in-row, right to left) needs
-            // nothing but C, so it runs on the auxiliary stream from here on, as a FIRST pass into a volume of its
-            // own (2 V of traffic instead of the 3 V of "S +="), beside the pre-pass and the sweep -- which at these
-            // D are bound by instruction issue, not by HBM; k_wta_t adds the two volumes while it stages them.
-            // debug 65536: the fifth path after the sweep, accumulating into S (A/B).
-            const bool two_vol = g.mode == 0 && !fused_wta && g.D <= 128 && !(e->debug & 4) && !(e->debug & 65536);
-            int16_t *S2 = nullptr;
-            if (two_vol) {
-                if ((rc = e->aggr2.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
-                S2 = (int16_t *)e->aggr2.p;
-            }
-            // D <= 64 (small-D schedule): the OTHER in-row path (left to right) needs nothing but C either.  It used to follow
-            // the element-wise vertical kernel as "S +=" on the main stream -- a chain of W1 dependent steps on the
-            // critical path of a latency-bound frame; now it runs as a FIRST pass into a third volume on a stream of its
-            // own, beside the per-row pre-pass and k_vert3_g, and the winner-take-all adds three volumes.
-            const bool three_vol = two_vol && rows4 && !(e->debug & SGM_DBG_IN_ROW_ON_MAIN_STREAM);
-            int16_t *S3 = nullptr;
-            if (three_vol) {
-                if ((rc = e->aggr3.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
-                S3 = (int16_t *)e->aggr3.p;
-            }
-            if (two_vol && do_pre) {
+            if (two_vol && do_pre && !five_vol) {
                 if (!e->aux) {
                     HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
                     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -873,7 +889,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             for (int pass = 0; pass < npass && do_mid; pass++) {
                 const int ydir = pass == 0 ? 1 : -1, xdir = ydir;
                 int16_t *bl = (int16_t *)(pass == 0 ? e->bndL.p : e->bndL2.p);
-                if (nbands > 1 && !(overlap && pass == 1) && !chain) {
+                if (nbands > 1 && !(overlap && pass == 1) && !chain && !five_vol) {
                     if ((rc = stage_begin(e, pass == 0 ? "prepass_dn" : "prepass_up"))) return rc;
                     const int nl = launch_prepass(xdir, ydir, bl, st);
                     KCHECK();
@@ -901,24 +917,36 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                     HIP_TRY(hipMemsetAsync(e->chain_ctl.p, 0, ctl_bytes, st));
                     stage_break(e);
                 }
-                if ((rc = stage_begin(e, chain ? (pass == 0 ? "chain_dn" : "chain_up")
+                if ((rc = stage_begin(e, five_vol ? "paths5" : chain ? (pass == 0 ? "chain_dn" : "chain_up")
                                                : (pass == 0 ? "sweep_dn" : (fused_wta ? "sweep_up_wta" : "sweep_up"))))) return rc;
                 // per-row state written by the grouped pre-pass: role-major; by the single-direction kernel (debug 16): band layout
                 const int rmaj = (e->debug & 16) ? 0 : 1;
-                if (rows4) {
+                if (five_vol) {
+                    // D <= 64, MODE_SGBM: all five directions in one launch, one volume each (k_paths5_g)
+                    const int G = 64 / GWs, nr = (H + G - 1) / G, nl = (g.W1 + G - 1) / G;
+                    // (Rows and lines as two launches one after the other, in either order, were measured too: 4K D=16 0.60 / 0.59 ms
+                    // against 0.57 ms for the single launch; 720p D=64 0.21 / 0.22 against 0.19 -- the stage moves 6 ... 10 V
+                    // and is not far from what HBM delivers for such partial-line traffic)
+                    dim3 grid(2 * nr + 3 * nl), block(64);
+                    if (GWs == 8) hipLaunchKernelGGL((k_paths5_g<8, false>), grid, block, 0, st, g, xdir, ydir, C, S, S4, S5, S2, S3, nr);
+                    else if (GWs == 16) hipLaunchKernelGGL((k_paths5_g<16, false>), grid, block, 0, st, g, xdir, ydir, C, S, S4, S5, S2, S3, nr);
+                    else if (g.D < 64) hipLaunchKernelGGL((k_paths5_g<32, true>), grid, block, 0, st, g, xdir, ydir, C, S, S4, S5, S2, S3, nr);
+                    else hipLaunchKernelGGL((k_paths5_g<32, false>), grid, block, 0, st, g, xdir, ydir, C, S, S4, S5, S2, S3, nr);
+                } else if (rows4) {
                     // D <= 64, band height 1: the three directions from the previous row are element-wise given the
                     // pre-pass state of every row (k_vert3_g, one streaming pass over all pixels); only the in-row
                     // direction is a recurrence (k_rows_g, S +=)
                     dim3 grid((g.W1 + 255) / 256, H), block(256);
                     const int16_t *bq = (const int16_t *)bl;
-#define SGM_VERT(GW_)                                                                                            \
+#define SGM_VERT(GW_, PART_)                                                                                     \
     do {                                                                                                         \
-        if (pass == 0) hipLaunchKernelGGL((k_vert3_g<GW_, PATH_FIRST>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
-        else hipLaunchKernelGGL((k_vert3_g<GW_, PATH_ACCUM>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
+        if (pass == 0) hipLaunchKernelGGL((k_vert3_g<GW_, PATH_FIRST, PART_>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
+        else hipLaunchKernelGGL((k_vert3_g<GW_, PATH_ACCUM, PART_>), grid, block, 0, st, g, xdir, ydir, C, S, bq, rmaj); \
     } while (0)
-                    if (GWs == 8) SGM_VERT(8);
-                    else if (GWs == 16) SGM_VERT(16);
-                    else SGM_VERT(32);
+                    if (GWs == 8) SGM_VERT(8, false);
+                    else if (GWs == 16) SGM_VERT(16, false);
+                    else if (g.D < 64) SGM_VERT(32, true);
+                    else SGM_VERT(32, false);
 #undef SGM_VERT
                     if (!three_vol) launch_rows_grouped(g, H, GWs, xdir, PATH_ACCUM, C, S, 1, wta, st);
                 } else if (chain) {
@@ -930,7 +958,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 if ((rc = stage_end(e, 1))) return rc;
             }
             if (!do_post) return SGM_OK;
-            if (two_vol) {
+            if (two_vol && !five_vol) {
                 HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
                 if (three_vol) HIP_TRY(hipStreamWaitEvent(st, e->ev_join2, 0));
                 stage_break(e);
@@ -959,7 +987,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             HIP_TRY(hipFuncSetAttribute((const void *)k_wta_t<POSW_, LG_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                                    \
         hipLaunchKernelGGL((k_wta_t<POSW_, LG_>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,              \
-                           (const int16_t *)nullptr, (const int16_t *)nullptr);                                        \
+                           (const int16_t *)nullptr, (const int16_t *)nullptr, (const int16_t *)nullptr,              \
+                           (const int16_t *)nullptr);                                                                  \
     } while (0)
 #define SGM_WTA2(POSW_, LG_)                                                                                           \
     do {                                                                                                               \
@@ -967,11 +996,19 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             HIP_TRY(hipFuncSetAttribute((const void *)k_wta_t<POSW_, LG_, 2>,                                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
         hipLaunchKernelGGL((k_wta_t<POSW_, LG_, 2>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,           \
-                           (const int16_t *)S2, (const int16_t *)nullptr);                                             \
+                           (const int16_t *)S2, (const int16_t *)nullptr, (const int16_t *)nullptr,                    \
+                           (const int16_t *)nullptr);                                                                  \
     } while (0)
 #define SGM_WTA3(POSW_, LG_)                                                                                           \
-    hipLaunchKernelGGL((k_wta_t<POSW_, LG_, 3>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,               \
-                       (const int16_t *)S2, (const int16_t *)S3)
+    do {                                                                                                               \
+        if (five_vol)                                                                                                  \
+            hipLaunchKernelGGL((k_wta_t<POSW_, LG_, 5>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,       \
+                               (const int16_t *)S2, (const int16_t *)S3, (const int16_t *)S4, (const int16_t *)S5);   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_wta_t<POSW_, LG_, 3>), grid, block, lds, st, g, (const int16_t *)S, wta, npix,       \
+                               (const int16_t *)S2, (const int16_t *)S3, (const int16_t *)nullptr,                     \
+                               (const int16_t *)nullptr);                                                              \
+    } while (0)
 #define SGM_WTA3_LG(POSW_)                      \
     do {                                        \
         switch (lgc) {                          \
@@ -1013,6 +1050,10 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                         const int64_t n8 = (int64_t)g.rowsz * H / 8;  // rowsz = W1 * D is a multiple of 16
                         hipLaunchKernelGGL(k_add_sat, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, S, (const int16_t *)S2, n8);
                         if (three_vol) hipLaunchKernelGGL(k_add_sat, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, S, (const int16_t *)S3, n8);
+                        if (five_vol) {
+                            hipLaunchKernelGGL(k_add_sat, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, S, (const int16_t *)S4, n8);
+                            hipLaunchKernelGGL(k_add_sat, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, S, (const int16_t *)S5, n8);
+                        }
                     }
                 } else if (g.uniq < 100) SGM_WTA_LG(true);
                 else SGM_WTA_LG(false);
@@ -1173,7 +1214,7 @@ void sgm_destroy(sgm_engine *e)
     (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->aggr2, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2, &e->pstate, &e->pstate2,
                       &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
-                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom, &e->chain_ctl, &e->chain_err, &e->aggr3};
+                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom, &e->chain_ctl, &e->chain_err, &e->aggr3, &e->aggr4, &e->aggr5};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->aux2) {

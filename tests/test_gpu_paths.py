@@ -32,7 +32,7 @@ def test_large_blocks_and_high_prefilter_caps(H, W, D, bs, cap, mode):
         assert not bad, f"schedule {schedule}: " + "\n".join(bad)
 
 
-@pytest.mark.parametrize("debug", [8, 16, 32, 128, 16 | 32, 4, 4 | 16, 512, 65536, 2, 2048, 4096, 4096 | 16])
+@pytest.mark.parametrize("debug", [8, 16, 32, 128, 16 | 32, 4, 4 | 16, 512, 65536, 2, 2048, 4096, 4096 | 16, 8192, 8192 | 16])
 @pytest.mark.parametrize("H,W,D,bs,mode", [(45, 420, 256, 7, 1), (38, 300, 64, 5, 1), (41, 200, 16, 11, 0), (29, 640, 160, 5, 0)])
 def test_debug_switches_keep_results(debug, H, W, D, bs, mode):
     """8: k_vsum_ring with 4 int16 per thread; 16: the pre-pass as three launches of the single-direction
@@ -40,13 +40,34 @@ def test_debug_switches_keep_results(debug, H, W, D, bs, mode):
     downward pre-pass; 4: no lane groups; 65536: MODE_SGBM's fifth path after the sweep (S +=) instead of
     beside it into its own volume; 2 / 2048: winner-take-all fused into the last path kernel / always its own pass
     (csrc/sgm_debug.h); 4096: D <= 64, the left-to-right in-row path after the vertical kernel instead of beside it
-    into a third volume.  Results must not change; 256 (int16 cost pipeline) is in
+    into a third volume; 8192: D <= 64 MODE_SGBM, the per-row record + element-wise vertical kernel instead of one volume per
+    direction (k_lines3_g).  Results must not change; 256 (int16 cost pipeline) is in
     test_gpu_parity.py::test_both_winner_take_all_forms."""
     l, r, _ = synth.make_pair(H, W, D, 300 + debug)
     p = U.params(D, bs, 0, mode, speckleWindowSize=30, speckleRange=2)
     want, t = O.sgbm_compute(l, r, taps=True, **p)
     assert t["headroom_ok"]
     for dbg in (debug, debug | 256):
+        h = U.run_hip_with_taps(l, r, p, schedule=1, debug=dbg)
+        for k in ("C", "S", "disp_raw"):
+            assert np.array_equal(h[k], t[k]), (dbg, k)
+        assert np.array_equal(h["disp"], want), dbg
+        assert U.headroom_equal(h, t), (dbg, h["headroom"], t["max_cost_plus_p2"], t["max_delta"])
+
+
+@pytest.mark.parametrize("H,W,D", [(130, 100, 32), (90, 120, 48), (200, 56, 16), (50, 19, 16), (61, 24, 16), (7, 300, 64),
+                                   (1, 90, 16), (2, 90, 32), (95, 150, 64), (300, 81, 16)])
+def test_small_d_line_walks(H, W, D):
+    """D <= 64, MODE_SGBM: the three directions from the row above are walked along their lines, several lines per
+    wave (k_lines3_g: one volume per direction; debug 8192: k_prepass3_g + k_vert3_g through the per-row record).  A
+    line that leaves the image re-enters on the other side with a fresh state; the kernels find those steps with
+    scalar counters modulo the row width.  Frames taller than wide (several wraps per line), narrower than the
+    lines of one wave (W1 = 3, 8 lines per wave), D = 48 (idle lanes inside a group), one and two rows."""
+    l, r, _ = synth.make_pair(H, W, D, 4000 + H + W)
+    p = U.params(D, 3, 0, 0, speckleWindowSize=30, speckleRange=2)
+    want, t = O.sgbm_compute(l, r, taps=True, **p)
+    assert t["headroom_ok"]
+    for dbg in (0, 8192, 4096):
         h = U.run_hip_with_taps(l, r, p, schedule=1, debug=dbg)
         for k in ("C", "S", "disp_raw"):
             assert np.array_equal(h[k], t[k]), (dbg, k)

@@ -1,16 +1,18 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -m pytest tests/test_gpu_chain.py -x -q 2>&1 | tail -3
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_paths.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q > gpurun_out/session_pytest.log 2>&1; rc=$?
+tail -5 gpurun_out/session_pytest.log
+[ $rc -eq 0 ] || exit $rc
 run() {
   echo "== $*"
-  timeout -k 10 300 python bench.py --workload $1 $2 $3 $4 $5 $6 $7 $8 --stages --no-cpu-baseline --no-latency-mode 2>&1 | python -c "
+  timeout -k 10 300 python bench.py --workload $1 --stages --no-cpu-baseline --no-latency-mode --steps 40 --warmup 5 2>&1 | python -c "
 import sys,json
+o=[]
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('ms/step',round(d['ms_per_step'],3),'ms/pair',round(d['ms_per_pair'],3),'pairs/s',round(d['pairs_per_s'],2))
-    elif 'chain' in l or 'sum' in l: print(l.rstrip())
+        d=json.loads(l); o.append('ms/pair %.3f' % d['ms_per_pair'])
+    elif l.startswith('  ') and not 'sum' in l: o.append(' '.join(l.split()[:2]))
+print(' | '.join(o))
 "
 }
-run c1t
-run c4t
-run c4t64
-run c3c5x12
+run nb && run c1 && run c1x8 && run c1t && run tiny

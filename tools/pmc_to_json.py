@@ -26,6 +26,7 @@ STAGE_KERNEL = [  # stage -> regex on the demangled kernel name
     ("features", r"k_features"), ("cost_pix", r"k_pix(<|_px)"), ("cost_box", r"k_box_u8"),
     ("cost_hsum", r"k_hsum"), ("cost_vsum", r"k_vsum"),
     ("prepass", r"k_prepass3|k_path<\d+, \w+, 3"),
+    ("paths5", r"k_paths5_g"),
     ("chain_dn", r"k_sweep_chain<\d+, \w+, 0"), ("chain_up", r"k_sweep_chain<\d+, \w+, 1"),
     ("sweep_dn", r"k_sweep<\d+, \w+, 0|k_vert3_g<\d+, 0"), ("sweep_up", r"k_sweep<\d+, \w+, 1|k_vert3_g<\d+, 1"),
     ("sweep_up_wta", r"k_sweep<\d+, \w+, 2"), ("path_W_wta", r"k_rows_g<\d+, \d+, \w+, 2"), ("path_W", r"k_rows_g<\d+, \d+, \w+, [01]"),
