@@ -413,16 +413,22 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
 // the vertical running sums keep the last 2R+2 hs vectors of each column in statically indexed
 // register rings.  2.5 bytes read per output byte pair instead of 7: the first version (one column
 // per wave) was bound by L2 traffic.
-template <int R, int NP>
+// GW < 64 (D <= 64, NP = 1): lane groups as in kernels_group.h -- a wave takes 64 / GW groups of XC columns, GW lanes
+// span the disparities of a group (round 3: small D used the int16 pipeline, 3 V more traffic, because lanes spanning
+// D = 16 would idle 7/8 of this kernel).
+template <int R, int NP, int GW = 64>
 __global__ __launch_bounds__(256) void k_box_u8(Geom g, const uint8_t *__restrict__ pix, int16_t *__restrict__ C, int RB)
 {
     constexpr int RS = R <= 1 ? 4 : (R <= 3 ? 8 : 16);  // pow2 >= 2R+2
     constexpr int XC = 4, NT = 2 * R + XC;
     constexpr int NQ = (NP + 1) / 2;  // dwords of bytes per lane and column
-    const int lane = threadIdx.x & 63;
-    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * XC;
+    constexpr int G = 64 / GW;
+    static_assert(GW == 64 || NP == 1, "lane groups: D <= 64");
+    const int lane = GW == 64 ? (int)(threadIdx.x & 63) : (int)(threadIdx.x & 63) % GW;  // index along the disparities
+    const int xw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * XC * G;                       // first column of the wave
+    const int x0 = GW == 64 ? xw : xw + (int)((threadIdx.x & 63) / GW) * XC;             // ... of this lane's group
     const int W1 = g.W1, D = g.D, H = g.H;
-    if (x0 >= W1) return;
+    if (xw >= W1) return;  // (the whole wave; a GROUP past the row end loads clamped columns and stores nothing)
     const bool active = 2 * NP * lane < D;
     const int y0 = (int)blockIdx.y * RB, y1 = min(y0 + RB, H);
     const int row_bytes = W1 * D;

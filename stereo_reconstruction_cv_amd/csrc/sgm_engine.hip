@@ -578,10 +578,20 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         };
         // Byte pipeline (default): k_pix writes the per-pixel cost as uint8, k_box_u8 does the whole box
         // filter from it.  Needs a window radius 1..5 (instantiations), a cost that fits a byte, and a
-        // pix volume below the 2 GiB a buffer descriptor spans here; for D <= 64 (mostly idle lanes in
-        // both kernels) the int16 pipeline is faster.  debug 256: the int16 pipeline always.
-        const bool byte_cost = !(e->debug & 256) && g.D > 64 && g.SW2 >= 1 && g.SW2 <= 5 && 2 * g.ftzero + 63 <= 255 &&
-                               (int64_t)H * g.rowsz < (int64_t)0x7ff00000;
+        // pix volume below the 2 GiB a buffer descriptor spans here.  D <= 64: k_box_u8 in lane groups (several columns'
+        // disparities side by side in a wave); the per-pixel cost comes from k_pix_px (D <= 32, one thread per pixel) or
+        // k_pix (D = 48, 64: half its lanes idle, still less than the int16 pipeline's 3 V more traffic).
+        // debug 256: the int16 pipeline always; debug 4 (no lane groups): the int16 pipeline for D <= 64.
+        const bool byte_cost = !(e->debug & 256) && (g.D > 64 || !(e->debug & 4)) && g.SW2 >= 1 && g.SW2 <= 5 && g.SH2 == g.SW2 &&
+                               2 * g.ftzero + 63 <= 255 && (int64_t)H * g.rowsz < (int64_t)0x7ff00000;
+        const int GWc = g.D > 64 ? 64 : (g.D <= 16 ? 8 : (g.D <= 32 ? 16 : 32));  // lane-group width of k_box_u8
+        const int cpw = 16 * (64 / GWc);  // columns per workgroup of k_box_u8: 4 waves x (64 / GW groups) x 4 columns
+        // rows per band of k_box_u8 (a band re-reads 2 * SH2 rows above it; multiples of 16: the register rings): 96, less
+        // on frames too small to fill the chip with bands that tall
+        int RBb = 96;
+        for (int cand : {48, 32, 16})
+            if ((int64_t)((g.W1 + cpw - 1) / cpw) * ((H + RBb - 1) / RBb) * 4 < 1024) RBb = cand;
+        const int nvbb = (H + RBb - 1) / RBb;
         // per-pixel cost of rows [y_lo, y_hi) / block cost of the nb bands of RB rows, on stream `on`
         auto launch_pix = [&](int y_lo, int y_hi, hipStream_t on) {
             const int nj = XL + 2;
@@ -590,19 +600,26 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             const size_t lds = (size_t)lrec_b + 6 * (size_t)seg_l;
             dim3 grid((unsigned)((int64_t)(y_hi - y_lo) * nchunks)), block(64);
             uint8_t *px = (uint8_t *)HS;
+            if (g.D <= 32) {  // one thread per pixel (whole frame; callers pass [0, H))
+                dim3 gridp((g.W1 + 255) / 256, H), blockp(256);
+                hipLaunchKernelGGL(k_pix_px, gridp, blockp, (size_t)6 * (256 + g.D), on, g, lrec, rpl, px);
+            } else
             if (g.NP == 1) hipLaunchKernelGGL(k_pix<1>, grid, block, lds, on, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l, y_lo);
             else if (g.NP == 2) hipLaunchKernelGGL(k_pix<2>, grid, block, lds, on, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l, y_lo);
             else hipLaunchKernelGGL(k_pix<4>, grid, block, lds, on, g, lrec, rpl, px, XL, nchunks, lrec_b, seg_l, y_lo);
         };
         auto launch_box = [&](int nb, hipStream_t on) {
-            dim3 grid((g.W1 + 15) / 16, nb), block(256);  // 4 waves x 4 columns per workgroup
+            dim3 grid((g.W1 + cpw - 1) / cpw, nb), block(256);
             const uint8_t *px = (const uint8_t *)HS;
             int16_t *cp2 = (int16_t *)e->cost.p;
 #define SGM_BOX(R_)                                                                                        \
     case R_:                                                                                               \
-        if (g.NP == 1) hipLaunchKernelGGL((k_box_u8<R_, 1>), grid, block, 0, on, g, px, cp2, RB);  \
-        else if (g.NP == 2) hipLaunchKernelGGL((k_box_u8<R_, 2>), grid, block, 0, on, g, px, cp2, RB); \
-        else hipLaunchKernelGGL((k_box_u8<R_, 4>), grid, block, 0, on, g, px, cp2, RB);            \
+        if (GWc == 8) hipLaunchKernelGGL((k_box_u8<R_, 1, 8>), grid, block, 0, on, g, px, cp2, RBb);        \
+        else if (GWc == 16) hipLaunchKernelGGL((k_box_u8<R_, 1, 16>), grid, block, 0, on, g, px, cp2, RBb); \
+        else if (GWc == 32) hipLaunchKernelGGL((k_box_u8<R_, 1, 32>), grid, block, 0, on, g, px, cp2, RBb); \
+        else if (g.NP == 1) hipLaunchKernelGGL((k_box_u8<R_, 1>), grid, block, 0, on, g, px, cp2, RBb);  \
+        else if (g.NP == 2) hipLaunchKernelGGL((k_box_u8<R_, 2>), grid, block, 0, on, g, px, cp2, RBb); \
+        else hipLaunchKernelGGL((k_box_u8<R_, 4>), grid, block, 0, on, g, px, cp2, RBb);            \
         break;
             switch (g.SW2) {
                 SGM_BOX(1)
@@ -653,7 +670,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             KCHECK();
             if ((rc = stage_end(e, 1))) return rc;
             if ((rc = stage_begin(e, "cost_box"))) return rc;
-            launch_box(nvb, st);
+            launch_box(nvbb, st);
             KCHECK();
             if ((rc = stage_end(e, 1))) return rc;
         } else {
