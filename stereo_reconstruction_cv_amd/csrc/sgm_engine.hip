@@ -638,7 +638,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         const int GWs = (e->debug & 4) ? 64 : group_width(g, H);
         // Throughput mode (schedule 2) takes D = 48 .. 64 through the chained sweeps all the same (half the lanes idle, but
         // 7 V of traffic per pair instead of the 22 V of the per-row state: batches of small frames are bound by HBM --
-        // 32 pairs 720p D=64: 0.42 against 0.57 ms per pair); D <= 32 keeps the small-D kernels in every mode.
+        // 64 pairs 720p D=64: 0.38 against 0.55 ms per pair); D <= 32 keeps the small-D kernels in every mode.
         const bool rows4 = GWs <= 32 && e->sweep_rows <= 0 && !(e->schedule == 2 && GWs == 32) &&
                            (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
         const int npass = g.mode == 1 ? 2 : 1;
@@ -941,9 +941,11 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
                 if (five_vol) {
                     // D <= 64, MODE_SGBM: all five directions in one launch, one volume each (k_paths5_g)
                     const int G = 64 / GWs, nr = (H + G - 1) / G, nl = (g.W1 + G - 1) / G;
-                    // (Rows and lines as two launches one after the other, in either order, were measured too: 4K D=16 0.60 / 0.59 ms
-                    // against 0.57 ms for the single launch; 720p D=64 0.21 / 0.22 against 0.19 -- the stage moves 6 ... 10 V
-                    // and is not far from what HBM delivers for such partial-line traffic)
+                    // (Measured beside it: rows and lines as two launches one after the other, in either order -- 4K D=16 0.60 /
+                    // 0.59 ms against 0.57 ms, 720p D=64 0.21 / 0.22 against 0.19; occupancy capped at one or two waves per SIMD
+                    // through an LDS allocation -- 0.66 against 0.65 ms, 0.23 / 0.27 against 0.20.  Neither the order nor the
+                    // number of waves per SIMD matters: the stage moves 6 ... 10 V in 32-byte pieces per row and is bound by
+                    // the memory side)
                     dim3 grid(2 * nr + 3 * nl), block(64);
                     if (GWs == 8) hipLaunchKernelGGL((k_paths5_g<8, false>), grid, block, 0, st, g, xdir, ydir, C, S, S4, S5, S2, S3, nr);
                     else if (GWs == 16) hipLaunchKernelGGL((k_paths5_g<16, false>), grid, block, 0, st, g, xdir, ydir, C, S, S4, S5, S2, S3, nr);

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 run() {
-  echo "== $* (SPLIT=$SGM_EXP_SPLIT)"
+  echo "== $* (LDS5=$SGM_EXP_LDS5)"
   timeout -k 10 300 python bench.py --workload $1 --stages --no-cpu-baseline --no-latency-mode --steps 40 --warmup 5 2>&1 | python -c "
 import sys,json
 o=[]
@@ -12,7 +12,7 @@ print(' | '.join(o))
 "
 }
 for w in nb c1 c1x8; do
-for sp in 0 1 2; do
-export SGM_EXP_SPLIT=$sp
+for v in 0 20000 27000 40000 54000 81000; do
+export SGM_EXP_LDS5=$v
 run $w || exit 1
 done; done
