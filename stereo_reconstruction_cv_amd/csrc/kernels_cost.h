@@ -307,17 +307,14 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
                                             int y_base /* the launch covers rows y_base .. y_base + gridDim.x / nchunks - 1 */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint2 *lds_lrec = reinterpret_cast<uint2 *>(smem);
-    uint8_t *seg = smem + lrec_bytes;
+    uint8_t *seg = smem + lrec_bytes;  // (the first lrec_bytes are unused since the left records are read by scalar loads)
     const int lane = threadIdx.x;
     const int unit = blockIdx.x;
     const int yr = __builtin_amdgcn_readfirstlane(unit / nchunks), ck = unit - yr * nchunks;  // (uniform: see uniform_rsrc)
     const int y = y_base + yr;
     const int W1 = g.W1, W = g.W;
     const int j0 = ck * XL, j1 = min(j0 + XL, W1) - 1;
-    const int nj = j1 - j0 + 1;
     const bool active = 2 * NP * lane < g.D;
-    for (int k = lane; k < nj; k += 64) lds_lrec[k] = lrec[(int64_t)y * W + (j0 + k + g.minX1)];
     {
         const int base_j1 = W - 1 - (j1 + g.minX1) + g.minD;  // mirrored position of (column j1, disparity index 0)
         const int len = (j1 - j0) + 128 * NP;
@@ -344,14 +341,22 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
     const int row_bytes = W1 * g.D;
     const __amdgpu_buffer_rsrc_t orow = uniform_rsrc(pix, (int64_t)y * row_bytes, row_bytes);
     const int voff = active ? 2 * NP * lane : row_bytes;
-    int tap[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) tap[c] = c * seg_len + 2 * NP * lane + (j1 - j0);
-    int recp = 0;
-    asm volatile("" : "+v"(recp));  // keep the (wave-uniform) record in VGPRs: v_perm splats, no scalar unpack
+    // The left pixel's record is the same for every lane: it is read with SCALAR loads straight from `lrec` and its six
+    // bytes are splat into packed pairs on the scalar unit -- these launches run several waves per SIMD, so scalar
+    // work rides beside the other waves' vector instructions, and the kernel is bound by the vector ALU (round 3:
+    // 58 -> 47 vector instructions per column at NP = 2; the six v_perm splats of a VGPR-held record and the LDS tap
+    // address additions -- now immediates on a per-iteration base -- were a fifth of them).
+    // (constant address space: k_features wrote the records before this launch; hipcc uses scalar loads only there -- through
+    // the global pointer the buffer stores below count as possible writers and the loads stay vector loads)
+    typedef const __attribute__((address_space(4))) v2u32 *crec_ptr;  // (a plain vector type: HIP's uint2 class has no constructor from that address space)
+    // (wave-uniform address; v_readfirstlane on both halves, or the 64-bit row arithmetic keeps it in VGPRs: see uniform_rsrc)
+    const uint64_t la = (uint64_t)(uintptr_t)(lrec + ((int64_t)y * W + (j0 + g.minX1)));
+    const uint32_t la_lo = __builtin_amdgcn_readfirstlane((uint32_t)la), la_hi = __builtin_amdgcn_readfirstlane((uint32_t)(la >> 32));
+    const crec_ptr lrow = (crec_ptr)(uintptr_t)(((uint64_t)la_hi << 32) | la_lo);  // (uint32_t first: the builtin returns int)
+    auto splat = [](uint32_t v) __attribute__((always_inline)) { return v | (v << 16); };
     int so = j0 * g.D;
     // one column: shift the six windows by the new bytes nw[] (not for the chunk's first column), cost, store
-    auto column = [&](int j, bool shift, const uint32_t (&nw)[6]) {
+    auto column = [&](const v2u32 rec, bool shift, const uint32_t (&nw)[6]) __attribute__((always_inline)) {
         if (shift) {
 #pragma unroll
             for (int c = 0; c < 6; c++) {
@@ -360,9 +365,8 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
                 w[c][0] = (w[c][0] << 16) | nw[c];
             }
         }
-        const uint2 rec = lds_lrec[recp + (j - j0)];
-        const uint32_t U = splat_byte<0>(rec.x), U0 = splat_byte<1>(rec.x), U1 = splat_byte<2>(rec.x);
-        const uint32_t R = splat_byte<0>(rec.y), R0 = splat_byte<1>(rec.y), R1 = splat_byte<2>(rec.y);
+        const uint32_t U = splat(rec.x & 0xffu), U0 = splat((rec.x >> 8) & 0xffu), U1 = splat((rec.x >> 16) & 0xffu);
+        const uint32_t R = splat(rec.y & 0xffu), R0 = splat((rec.y >> 8) & 0xffu), R1 = splat((rec.y >> 16) & 0xffu);
         uint32_t pv[NP];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -384,24 +388,36 @@ __global__ __launch_bounds__(64) void k_pix(Geom g, const uint2 *__restrict__ lr
         so += g.D;
     };
     const uint32_t none[6] = {0, 0, 0, 0, 0, 0};
-    column(j0, false, none);
+    column(lrow[0], false, none);
     int j = j0 + 1;
+    // per-lane LDS address of the six planes' new byte for column j + 3 (the last of a block of four); the bytes of
+    // columns j .. j + 3 are then at immediate offsets 3 .. 0
+    int tp[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) tp[c] = c * seg_len + 2 * NP * lane + (j1 - j0) - (j - j0) - 3;
     // four columns per iteration: their 24 window bytes are read first (one counted wait instead of a
     // full lgkmcnt(0) drain per column), then the four columns are computed from registers
     for (; j + 3 <= j1; j += 4) {
         uint32_t nb[4][6];
+        v2u32 rec[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rec[u] = lrow[j - j0 + u];
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int c = 0; c < 6; c++) nb[u][c] = seg[tap[c] - (j + u - j0)];
+            for (int c = 0; c < 6; c++) nb[u][c] = seg[tp[c] + (3 - u)];
 #pragma unroll
-        for (int u = 0; u < 4; u++) column(j + u, true, nb[u]);
+        for (int c = 0; c < 6; c++) tp[c] -= 4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) column(rec[u], true, nb[u]);
     }
     for (; j <= j1; j++) {
         uint32_t nb[6];
 #pragma unroll
-        for (int c = 0; c < 6; c++) nb[c] = seg[tap[c] - (j - j0)];
-        column(j, true, nb);
+        for (int c = 0; c < 6; c++) nb[c] = seg[tp[c] + 3];
+#pragma unroll
+        for (int c = 0; c < 6; c++) tp[c] -= 1;
+        column(lrow[j - j0], true, nb);
     }
 }
 

@@ -1,18 +1,18 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_paths.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q > gpurun_out/session_pytest.log 2>&1; rc=$?
-tail -5 gpurun_out/session_pytest.log
+timeout -k 10 900 python -m pytest tests/test_gpu_paths.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_chain.py -x -q > gpurun_out/session_pytest.log 2>&1; rc=$?
+tail -3 gpurun_out/session_pytest.log
 [ $rc -eq 0 ] || exit $rc
 run() {
   echo "== $*"
-  timeout -k 10 300 python bench.py --workload $1 --stages --no-cpu-baseline --no-latency-mode --steps 40 --warmup 5 2>&1 | python -c "
+  timeout -k 10 300 python bench.py --workload $1 --stages --no-cpu-baseline --no-latency-mode --steps ${2:-10} --warmup 3 2>&1 | python -c "
 import sys,json
 o=[]
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); o.append('ms/pair %.3f' % d['ms_per_pair'])
-    elif l.startswith('  ') and not 'sum' in l: o.append(' '.join(l.split()[:2]))
+    elif l.startswith('  ') and not l.startswith('  sum'): o.append(' '.join(l.split()[:2]))
 print(' | '.join(o))
 "
 }
-run nb && run c1 && run c1x8 && run c1t && run tiny
+run c3c5x12 8 && run c3c5 20 && run c2 20 && run c4t 10 && run c1 40 && run c1t 10
