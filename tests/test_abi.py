@@ -126,3 +126,44 @@ def test_no_waterfall_loops_around_buffer_operations_in_the_hot_kernels():
             assert n <= 4, (name, n)      # the guarded tail's store offsets of the PATH_FIRST instantiations (last block of a row only)
         else:
             assert not re.search(r"k_sweep|k_prepass3|k_pix|k_hsum|k_path|k_wta_t", name), (name, n)
+
+
+def _largest_block_mix(text, name_part):
+    """instruction mix of the largest basic block (the unrolled steady-state loop) of the kernel whose mangled name contains name_part"""
+    from collections import Counter
+    for km in re.finditer(r"^(_Z\w+):\s*; @", text, flags=re.M):
+        if name_part not in km.group(1):
+            continue
+        body = text[km.end():text.index(".Lfunc_end", km.end())].split("\n")
+        blocks, cur = [], []
+        for l in body:
+            if re.match(r"^\.LBB", l):
+                blocks.append(cur)
+                cur = []
+            else:
+                cur.append(l)
+        blocks.append(cur)
+        big = max(blocks, key=len)
+        ins = [l.split()[0] for l in big if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+        return Counter(ins)
+    raise AssertionError(f"no kernel named *{name_part}* in the ISA")
+
+
+def test_single_wave_kernels_keep_their_instruction_count():
+    """Round 3: a wave issues one instruction of any kind per four cycles, and the lane-group kernels of the
+    small-D schedule run about one wave per SIMD -- their speed IS their instruction count.  What was removed must stay
+    removed: no v_readlane (SGPR spills of hoisted pixel offsets) and no v_cndmask (sentinel selects) in the steady-state
+    loop of the full-group in-row kernels, the group-edge sentinel as v_max_u32_dpp, the 32-lane minimum through
+    v_permlane16_swap; k_pix reads the left-pixel records with scalar loads and splats them on the scalar unit."""
+    csrc = os.path.join(ROOT, "stereo_reconstruction_cv_amd", "csrc")
+    text = open(os.path.join(csrc, "sgm_engine.s")).read()
+    for gw, valu_per_64 in ((8, 1050), (16, 1200), (32, 1300)):
+        m = _largest_block_mix(text, f"k_rows_gILi{gw}ELi1ELb0ELi0E")          # <GW, 1, full groups, PATH_FIRST>
+        assert m["buffer_load_dword"] == 64 and m["buffer_store_dword"] == 64, m   # the block is 64 pixel steps
+        assert m["v_readlane_b32"] == 0 and m["v_cndmask_b32_e64"] + m["v_cndmask_b32_e32"] == 0, (gw, m)
+        assert m["v_max_u32_dpp"] == 128, (gw, m)
+        assert sum(n for k, n in m.items() if k.startswith("v_")) <= valu_per_64, (gw, m)
+    assert _largest_block_mix(text, "k_rows_gILi32ELi1ELb0ELi0E")["v_permlane16_swap_b32_e32"] == 64
+    m = _largest_block_mix(text, "k_pixILi2E")                                    # four columns per iteration
+    assert m["s_load_dwordx8"] == 1 and m["buffer_store_dword"] == 4, m
+    assert sum(n for k, n in m.items() if k.startswith("v_")) <= 205, m
