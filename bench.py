@@ -12,7 +12,7 @@ Frames are sharded by rank with no data-path collective (weak scaling); the time
 bracketed by barrier + synchronize on both sides and the maximum over ranks is reported.  Rank 0
 prints ONE JSON line.
 
-Default workload "c3c5x12": a batch of twelve 3840x2160 pairs per GPU and step, D=256, blockSize=7,
+Default workload "c3c5x16": a batch of sixteen 3840x2160 pairs per GPU and step (16 engines of 13 GB; twelve: "c3c5x12"), D=256, blockSize=7,
 MODE_HH (8 paths) + LR check + sub-pixel + median + speckle + reprojection to XYZ (the union of
 BASELINE.json configs[2] and configs[4]), in THROUGHPUT MODE: chained sweeps without a boundary
 pre-pass, all pairs of the step through sgm_pipeline_batch_device (one sweep launch per pass for the
@@ -69,6 +69,10 @@ WORKLOADS = {
     "c3c5x12": (2160, 3840, 256, 7, 1, 12, True, 2, True,
                 "batch of twelve 3840x2160 D=256 bs=7 MODE_HH 8-path pairs per step (+ LR + subpixel + median + speckle + "
                 "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch"),
+    "c3c5x16": (2160, 3840, 256, 7, 1, 16, True, 2, True,
+                "batch of sixteen 3840x2160 D=256 bs=7 MODE_HH 8-path pairs per step (+ LR + subpixel + median + speckle + "
+                "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch (16 engines = 208 GB)"),
+    "c3c5x18": (2160, 3840, 256, 7, 1, 18, True, 2, True, "batch of eighteen 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject): 18 engines = 234 GB"),
     "c5x12": (2160, 3840, 256, 7, 0, 12, True, 2, True, "batch of twelve 4K D=256 5-path pairs per step + reproject, throughput mode"),
     "c4t": (1080, 1920, 128, 7, 0, 32, False, 2, True, "batch of 32 1920x1080 D=128 5-path pairs per step, throughput mode"),
     "c4t64": (1080, 1920, 128, 7, 0, 64, False, 2, True, "batch of 64 1920x1080 D=128 5-path pairs per step (all of BASELINE configs[3] on one GPU), throughput mode"),
@@ -76,7 +80,7 @@ WORKLOADS = {
     "tiny": (96, 480, 64, 7, 1, 2, True, 1, False, "96x480 D=64 MODE_HH x2 (launcher rehearsal only, not a BASELINE config)"),
     "tinyt": (96, 480, 128, 7, 1, 3, True, 2, True, "96x480 D=128 MODE_HH x3, throughput mode (launcher rehearsal only)"),
 }
-DEFAULT_WORKLOAD = "c3c5x12"
+DEFAULT_WORKLOAD = "c3c5x16"
 
 # stage (HIP-event bracket inside the engine) -> kernel that runs in it, for the roofline record
 STAGE_KERNEL = {
@@ -580,23 +584,24 @@ def main():
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            ls = torch.stack(d_left).to(comm_dev)
-            rs = torch.stack(d_right).to(comm_dev)
-            gl = sharding.gather_results(ls, ppg * world, dst=0)       # frames to rank 0 ...
-            gr = sharding.gather_results(rs, ppg * world, dst=0)
+            pi = min(ppg, 12)   # (rank 0 holds world * pi dense results per step in flight twice over: bounded beside the engines' 13 GB each)
+            ls = torch.stack(d_left[:pi]).to(comm_dev)
+            rs = torch.stack(d_right[:pi]).to(comm_dev)
+            gl = sharding.gather_results(ls, pi * world, dst=0)       # frames to rank 0 ...
+            gr = sharding.gather_results(rs, pi * world, dst=0)
             ingest_steps(gl, gr, 1)                                     # (buffers, communicators)
             barrier()
             t1 = time.perf_counter()
             res = ingest_steps(gl, gr, args.steps)                      # ... and through the pipeline
             barrier()
             idt = time.perf_counter() - t1
-            mine = torch.stack(d_disp).to(comm_dev)
-            ref = sharding.gather_results(mine, ppg * world, dst=0)
+            mine = torch.stack(d_disp[:pi]).to(comm_dev)
+            ref = sharding.gather_results(mine, pi * world, dst=0)
             if rank == 0:
                 got = res[-1][0] if isinstance(res[-1], tuple) else res[-1]
-                out["ingest_rank0"] = {"ok": bool(torch.equal(got, ref)), "frames_per_step": ppg * world, "xyz": bool(with_xyz),
+                out["ingest_rank0"] = {"ok": bool(torch.equal(got, ref)), "frames_per_step": pi * world, "xyz": bool(with_xyz),
                                        "backend": "gloo" if rehearse else "nccl", "steps": args.steps,
-                                       "ms_per_step": idt / args.steps * 1e3, "pairs_per_s": args.steps * ppg * world / idt,
+                                       "ms_per_step": idt / args.steps * 1e3, "pairs_per_s": args.steps * pi * world / idt,
                                        "note": "rank 0 owns every frame: scatter of step k + 2 and gather of step k beside the compute of "
                                                "step k + 1 (dist.IngestPipeline), every scatter / gather one batch of point-to-point transfers"}
         except Exception as ex:  # noqa: BLE001 -- the measurement above must survive whatever happens here
