@@ -12,7 +12,8 @@ Frames are sharded by rank with no data-path collective (weak scaling); the time
 bracketed by barrier + synchronize on both sides and the maximum over ranks is reported.  Rank 0
 prints ONE JSON line.
 
-Default workload "c3c5x16": a batch of sixteen 3840x2160 pairs per GPU and step (16 engines of 13 GB; twelve: "c3c5x12"), D=256, blockSize=7,
+Default workload "c3c5x17": a batch of seventeen 3840x2160 pairs per GPU and step (17 engines of 13 GB; the sweep launch then
+has 17 x 180 band tickets = 11.95 per persistent workgroup and no idle tail; twelve: "c3c5x12"), D=256, blockSize=7,
 MODE_HH (8 paths) + LR check + sub-pixel + median + speckle + reprojection to XYZ (the union of
 BASELINE.json configs[2] and configs[4]), in THROUGHPUT MODE: chained sweeps without a boundary
 pre-pass, all pairs of the step through sgm_pipeline_batch_device (one sweep launch per pass for the
@@ -69,9 +70,12 @@ WORKLOADS = {
     "c3c5x12": (2160, 3840, 256, 7, 1, 12, True, 2, True,
                 "batch of twelve 3840x2160 D=256 bs=7 MODE_HH 8-path pairs per step (+ LR + subpixel + median + speckle + "
                 "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch"),
-    "c3c5x16": (2160, 3840, 256, 7, 1, 16, True, 2, True,
-                "batch of sixteen 3840x2160 D=256 bs=7 MODE_HH 8-path pairs per step (+ LR + subpixel + median + speckle + "
-                "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch (16 engines = 208 GB)"),
+    "c3c5x16": (2160, 3840, 256, 7, 1, 16, True, 2, True, "batch of sixteen 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject)"),
+    "c3c5x14": (2160, 3840, 256, 7, 1, 14, True, 2, True, "batch of fourteen 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject)"),
+    "c3c5x17": (2160, 3840, 256, 7, 1, 17, True, 2, True,
+                "batch of seventeen 3840x2160 D=256 bs=7 MODE_HH 8-path pairs per step (+ LR + subpixel + median + speckle + "
+                "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch (17 engines = 221 GB; "
+                "17 x 180 bands = 11.95 tickets per persistent workgroup: no idle tail)"),
     "c3c5x18": (2160, 3840, 256, 7, 1, 18, True, 2, True, "batch of eighteen 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject): 18 engines = 234 GB"),
     "c5x12": (2160, 3840, 256, 7, 0, 12, True, 2, True, "batch of twelve 4K D=256 5-path pairs per step + reproject, throughput mode"),
     "c4t": (1080, 1920, 128, 7, 0, 32, False, 2, True, "batch of 32 1920x1080 D=128 5-path pairs per step, throughput mode"),
@@ -80,7 +84,7 @@ WORKLOADS = {
     "tiny": (96, 480, 64, 7, 1, 2, True, 1, False, "96x480 D=64 MODE_HH x2 (launcher rehearsal only, not a BASELINE config)"),
     "tinyt": (96, 480, 128, 7, 1, 3, True, 2, True, "96x480 D=128 MODE_HH x3, throughput mode (launcher rehearsal only)"),
 }
-DEFAULT_WORKLOAD = "c3c5x16"
+DEFAULT_WORKLOAD = "c3c5x17"
 
 # stage (HIP-event bracket inside the engine) -> kernel that runs in it, for the roofline record
 STAGE_KERNEL = {
