@@ -78,6 +78,7 @@ WORKLOADS = {
                 "17 x 180 bands = 11.95 tickets per persistent workgroup: no idle tail)"),
     "c3c5x18": (2160, 3840, 256, 7, 1, 18, True, 2, True, "batch of eighteen 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject): 18 engines = 234 GB"),
     "c5x12": (2160, 3840, 256, 7, 0, 12, True, 2, True, "batch of twelve 4K D=256 5-path pairs per step + reproject, throughput mode"),
+    "c5x17": (2160, 3840, 256, 7, 0, 17, True, 2, True, "batch of seventeen 4K D=256 5-path pairs per step + reproject, throughput mode (11.95 band tickets per workgroup)"),
     "c4t": (1080, 1920, 128, 7, 0, 32, False, 2, True, "batch of 32 1920x1080 D=128 5-path pairs per step, throughput mode"),
     "c4t64": (1080, 1920, 128, 7, 0, 64, False, 2, True, "batch of 64 1920x1080 D=128 5-path pairs per step (all of BASELINE configs[3] on one GPU), throughput mode"),
     "nb": (2160, 3840, 16, 11, 0, 1, True, 1, False, "3840x2160 D=16 bs=11 5-path + reproject (the notebook as run)"),
