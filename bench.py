@@ -190,9 +190,7 @@ def self_launch(n: int, argv: list[str]) -> int:
             sys.stderr.write(out)
     rc = p.wait()
     if line:
-        print(line)
-        if '"error": "timed out (watchdog)' in line:
-            rc = 0      # the ranks left through the ingest watchdog; the headline line is complete
+        print(line)     # (a stalled ingest leg leaves through its watchdog with a non-zero status: the line is printed, the run fails)
     elif rc == 0:
         rc = 1
         sys.stderr.write("bench.py: the ranks produced no JSON line\n")
@@ -237,6 +235,9 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--ingest", default="resident", choices=("resident", "rank0"),
                     help="rank0: frames start on rank 0; scatter / compute / gather pipeline over torch.distributed inside the timed region")
+    ap.add_argument("--xyz", default="dense", choices=("dense", "compact"),
+                    help="--ingest rank0 with a reprojecting workload: what travels back to rank 0 beside the int16 maps -- the dense "
+                         "XYZ image (12 bytes per pixel) or the valid points only, compacted on the GPU (main.ipynb:726-737)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the single-pair latency measurement that rides along at N = 1")
     ap.add_argument("--no-ingest-leg", action="store_true", help="N > 1, resident: skip the timed rank-0 ingest leg after the timed region")
@@ -386,33 +387,54 @@ def main():
     # ---- rank-0 ingest: scatter / compute / gather as a pipeline (dist.IngestPipeline) ----
     piped = batch and cstream is not None and not rehearse     # stream-ordered: nothing synchronises inside a step
 
-    def ingest_compute(l, r):
-        """compute() of the pipeline: this rank's shard [n, H, W] (on comm_dev) -> results on comm_dev; on the GPU box
-        nothing is synchronised here (the pipeline orders the engine's stream against the transfers with events)"""
-        with (torch.cuda.stream(cstream) if piped else _null()):
-            l, r = l.to(dev), r.to(dev)
-            n = l.shape[0]
-            disp = alloc((n, H, W), dtype=torch.int16, device=dev)
-            dispf = alloc((n, H, W), dtype=torch.float32, device=dev) if with_xyz else None
-            xyz = alloc((n, H, W, 3), dtype=torch.float32, device=dev) if with_xyz else None
-        if not piped:
-            sync()
-        used = enqueue([l[i] for i in range(n)], [r[i] for i in range(n)], [disp[i] for i in range(n)],
-                       [dispf[i] for i in range(n)] if with_xyz else None, [xyz[i] for i in range(n)] if with_xyz else None) if n else []
-        if not piped:
-            for e in used:
-                e.synchronize()
-        if with_xyz:
-            return disp.to(comm_dev), xyz.to(comm_dev)
-        return disp.to(comm_dev)
+    def make_ingest_compute(compact):
+        def ingest_compute(l, r):
+            """compute() of the pipeline: this rank's shard [n, H, W] (on comm_dev) -> results on comm_dev; on the GPU box
+            nothing is synchronised here (the pipeline orders the engine's stream against the transfers with events).
+            compact: (maps, valid points packed per frame, counts) instead of (maps, dense XYZ)"""
+            with (torch.cuda.stream(cstream) if piped else _null()):
+                l, r = l.to(dev), r.to(dev)
+                n = l.shape[0]
+                disp = alloc((n, H, W), dtype=torch.int16, device=dev)
+                dispf = alloc((n, H, W), dtype=torch.float32, device=dev) if with_xyz else None
+                xyz = alloc((n, H, W, 3), dtype=torch.float32, device=dev) if with_xyz else None
+                pts = alloc((n, H * W, 3), dtype=torch.float32, device=dev) if compact else None
+                cnt = alloc((n,), dtype=torch.int64, device=dev) if compact else None
+            if not piped:
+                sync()
+            used = enqueue([l[i] for i in range(n)], [r[i] for i in range(n)], [disp[i] for i in range(n)],
+                           [dispf[i] for i in range(n)] if with_xyz else None, [xyz[i] for i in range(n)] if with_xyz else None) if n else []
+            if compact and not mock:
+                if not batch:
+                    for e in used:   # (pairs on engines of their own: their XYZ images are not ordered against eng's stream)
+                        e.synchronize()
+                for i in range(n):   # on the engine's stream, behind the batch: no host round trip (sgm_compact_points_device_async)
+                    eng.compact_points_device_async(xyz[i].data_ptr(), dispf[i].data_ptr(), None, H * W, pts[i].data_ptr(), None,
+                                                    cnt[i:].data_ptr())
+            elif compact:
+                cnt.fill_(3)
+            if not piped:
+                for e in used + ([eng] if (compact and not mock and eng not in used) else []):
+                    e.synchronize()
+            if compact:
+                return disp.to(comm_dev), pts.to(comm_dev), cnt.to(comm_dev)
+            if with_xyz:
+                return disp.to(comm_dev), xyz.to(comm_dev)
+            return disp.to(comm_dev)
+        if not mock:
+            ingest_compute.check = eng.check      # IngestPipeline.drain: a chained sweep that gave up is reported, not handed on
+        return ingest_compute
 
-    def ingest_steps(all_l, all_r, nsteps):
+    def ingest_steps(all_l, all_r, nsteps, compact=False):
         """`nsteps` batches through the pipeline; rank 0 gets the list of per-step results"""
-        pipe = sharding.IngestPipeline(ingest_compute, src=0, device=comm_dev, compute_stream=cstream if piped else None)
+        pipe = sharding.IngestPipeline(make_ingest_compute(compact), src=0, device=comm_dev, compute_stream=cstream if piped else None,
+                                       compact=compact)
         for _ in range(nsteps):
             pipe.step(all_l, all_r)
             del pipe.done[:-1]          # (rank 0: only the last batch's results are looked at; 11 GB per batch at 8 GPUs)
         return pipe.drain()
+
+    want_compact = args.xyz == "compact" and with_xyz
 
     all_left = all_right = None
     if args.ingest == "rank0" and rank == 0:
@@ -421,7 +443,7 @@ def main():
 
     # ---- warm-up, timed region ----
     if args.ingest == "rank0":
-        ingest_steps(all_left, all_right, args.warmup)
+        ingest_steps(all_left, all_right, args.warmup, want_compact)
     else:
         for _ in range(args.warmup):
             run_local(d_left, d_right, d_disp, d_dispf, d_xyz)
@@ -429,12 +451,15 @@ def main():
     t0 = time.perf_counter()
     stage_acc = []
     if args.ingest == "rank0":
-        ingest_steps(all_left, all_right, args.steps)
+        ingest_steps(all_left, all_right, args.steps, want_compact)
     else:
         for _ in range(args.steps):
             stage_acc.extend(run_local(d_left, d_right, d_disp, d_dispf, d_xyz))
     barrier()
     dt = time.perf_counter() - t0
+    if not mock:
+        for e_ in engines:
+            e_.check()       # a chained sweep that gave up inside the timed region invalidates it: fail, do not report
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -572,7 +597,8 @@ def main():
 
     # ---- N > 1, resident: the rank-0 ingest path on hardware, timed over the same number of steps ----
     # (scatter / compute / gather pipeline over RCCL; never run on real multi-GPU hardware before the driver's scaling
-    #  run -- so a watchdog prints the finished headline line if it stalls, and any exception is reported, not raised)
+    #  run -- so a watchdog prints the finished headline line if it stalls and ENDS THE RUN WITH STATUS 3: a stalled
+    #  GPU or RCCL leg is a failure, not a success with a note; any exception is reported in the line, not raised)
     if world > 1 and args.ingest == "resident" and not args.no_ingest_leg:
         state = {"done": False}
 
@@ -585,30 +611,68 @@ def main():
             if rank == 0:
                 out["ingest_rank0"] = {"ok": False, "error": "timed out (watchdog): the scatter / gather leg did not finish"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            pi = min(ppg, 12)   # (rank 0 holds world * pi dense results per step in flight twice over: bounded beside the engines' 13 GB each)
+            # Pairs per rank: the timed region's, unless rank 0's memory says otherwise.  Rank 0 holds, beside everything the
+            # timed region allocated (engines, resident images and results): the gathered results of up to four batches
+            # (two in flight, one being finished, the last one kept) = 4 * world * per_pair_out, and the outputs of three
+            # local batches = 3 * local_out per pair.  80 % of what is free now may go there.
+            per_pair_out = H * W * (2 + (12 if with_xyz else 0))
+            local_out = H * W * (2 + (4 + 12 + 12 + 1 if with_xyz else 0))
+            pi = ppg
+            if not mock:
+                free_b, _tot = torch.cuda.mem_get_info(dev)
+                pi = int(max(1, min(ppg, (0.8 * free_b) // (4 * world * per_pair_out + 3 * local_out))))
+            if world > 1:
+                box = [pi]
+                dist.broadcast_object_list(box, src=0)
+                pi = int(box[0])
             ls = torch.stack(d_left[:pi]).to(comm_dev)
             rs = torch.stack(d_right[:pi]).to(comm_dev)
             gl = sharding.gather_results(ls, pi * world, dst=0)       # frames to rank 0 ...
             gr = sharding.gather_results(rs, pi * world, dst=0)
-            ingest_steps(gl, gr, 1)                                     # (buffers, communicators)
-            barrier()
-            t1 = time.perf_counter()
-            res = ingest_steps(gl, gr, args.steps)                      # ... and through the pipeline
-            barrier()
-            idt = time.perf_counter() - t1
             mine = torch.stack(d_disp[:pi]).to(comm_dev)
             ref = sharding.gather_results(mine, pi * world, dst=0)
+            legs = {}
+            for name, compact in (("dense", False),) + ((("compact", True),) if with_xyz else ()):
+                ingest_steps(gl, gr, 1, compact)                              # (buffers, communicators)
+                barrier()
+                t1 = time.perf_counter()
+                res = ingest_steps(gl, gr, args.steps, compact)               # ... and through the pipeline
+                barrier()
+                idt = time.perf_counter() - t1
+                rec = None
+                if compact and not mock:
+                    # what the compacted gather must equal: boolean indexing on this rank's resident XYZ (main.ipynb:726-737)
+                    cnt_loc = torch.stack([(torch.isfinite(d_xyz[i][..., 0]) & (d_dispf[i] > 0)).sum() for i in range(pi)]).to(torch.int64)
+                    cnt_ref = sharding.gather_results(cnt_loc.to(comm_dev), pi * world, dst=0)
+                if rank == 0:
+                    last = res[-1]
+                    got = last[0] if isinstance(last, tuple) else last
+                    ok = bool(torch.equal(got, ref))
+                    rec = {"ok": ok, "ms_per_step": idt / args.steps * 1e3, "pairs_per_s": args.steps * pi * world / idt}
+                    if compact:
+                        pts, counts = last[-2], last[-1]
+                        rec["points_per_pair"] = float(counts.float().mean())
+                        rec["bytes_per_pair_gathered"] = float(counts.float().mean()) * 12 + H * W * 2
+                        if not mock:
+                            m0 = torch.isfinite(d_xyz[0][..., 0]) & (d_dispf[0] > 0)
+                            rec["ok"] = bool(ok and torch.equal(counts.cpu(), cnt_ref.cpu()) and torch.equal(pts[0].to(dev), d_xyz[0][m0]))
+                    else:
+                        rec["bytes_per_pair_gathered"] = per_pair_out
+                legs[name] = rec
             if rank == 0:
-                got = res[-1][0] if isinstance(res[-1], tuple) else res[-1]
-                out["ingest_rank0"] = {"ok": bool(torch.equal(got, ref)), "frames_per_step": pi * world, "xyz": bool(with_xyz),
-                                       "backend": "gloo" if rehearse else "nccl", "steps": args.steps,
-                                       "ms_per_step": idt / args.steps * 1e3, "pairs_per_s": args.steps * pi * world / idt,
+                out["ingest_rank0"] = {"ok": all(r["ok"] for r in legs.values()), "frames_per_step": pi * world, "pairs_per_rank": pi,
+                                       "xyz": bool(with_xyz), "backend": "gloo" if rehearse else "nccl", "steps": args.steps,
+                                       # (the dense leg's figures at the top level, as in earlier rounds)
+                                       "ms_per_step": legs["dense"]["ms_per_step"], "pairs_per_s": legs["dense"]["pairs_per_s"],
+                                       **legs,
                                        "note": "rank 0 owns every frame: scatter of step k + 2 and gather of step k beside the compute of "
-                                               "step k + 1 (dist.IngestPipeline), every scatter / gather one batch of point-to-point transfers"}
+                                               "step k + 1 (dist.IngestPipeline), every scatter / gather one batch of point-to-point transfers; "
+                                               "dense = int16 maps + XYZ images travel back, compact = maps + the valid points only "
+                                               "(compacted on the GPU, counts one step ahead of the points)"}
         except Exception as ex:  # noqa: BLE001 -- the measurement above must survive whatever happens here
             if rank == 0:
                 out["ingest_rank0"] = {"ok": False, "error": f"{type(ex).__name__}: {ex}"[:500]}

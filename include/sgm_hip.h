@@ -29,6 +29,7 @@
  *                           the pairs of a batch share one chained sweep launch per pass     main.ipynb:780-797
  *   sgm_get_headroom     <- (no counterpart) tells the caller whether the last compute stayed inside
  *                           the int16 regime in which OpenCV's own arithmetic is exact
+ *   sgm_check, sgm_trim  <- (no counterpart) status of a stream-ordered engine; memory of the batch entries' groups
  *
  * Conventions: plain pointers and sizes, no C++ types, no exceptions across the boundary.
  * Every function returns 0 on success or a negative sgm_status; sgm_last_error() returns a
@@ -48,7 +49,8 @@
 extern "C" {
 #endif
 
-#define SGM_ABI_VERSION 3   /* 2: sgm_get_headroom, SGM_OPT_PREPASS_ROWS (round 2); 3: sgm_pipeline_batch_device, SGM_OPT_CHAIN_WGS, schedule 2 */
+#define SGM_ABI_VERSION 4   /* 2: sgm_get_headroom, SGM_OPT_PREPASS_ROWS (round 2); 3: sgm_pipeline_batch_device, SGM_OPT_CHAIN_WGS, schedule 2;
+                             * 4: sgm_check, sgm_trim, sgm_compact_points_device_async, SGM_OPT_GROUP_MAX (round 4) */
 
 typedef enum {
     SGM_OK = 0,
@@ -95,6 +97,8 @@ typedef enum {
     SGM_OPT_SWEEP_ROWS = 3,  /* rows per band of the fused sweep; 0 = automatic                  */
     SGM_OPT_CHAIN_WGS = 6,   /* schedule 2: workgroups (bands in flight) per sweep launch; 0 = automatic       */
     SGM_OPT_PREPASS_ROWS = 5, /* rows per chunk (= launch) of the boundary pre-pass; 0 = automatic (about 135, a multiple of 8) */
+    SGM_OPT_GROUP_MAX = 7,   /* schedule 2, batch entries: pairs per chained launch (= internal engines kept, about 9 GB each at
+                              * 4K D=256); 0 = automatic: as many as device memory holds beside a reserve, up to 64; 1 = never chain */
     /* 4 = SGM_OPT_DEBUG: A/B switches for measurements -- not part of this interface (csrc/sgm_debug.h) */
     SGM_OPT_RESERVED_4 = 4
 } sgm_option;
@@ -122,8 +126,10 @@ int sgm_geometry(const sgm_params *params, int W, int *minX1, int *W1);
 /* ---- host-pointer entry points (blocking) ---- */
 int sgm_compute(sgm_engine *e, const uint8_t *left, const uint8_t *right, int H, int W,
                 int64_t stride_bytes, int16_t *disp_out /* H*W */);
-/* N dense pairs (tight rows); up to three pairs in flight on internal peer engines, images and disparity maps
- * staged through page-locked buffers inside the engine (pageable caller memory is fine) */
+/* N dense pairs (tight rows) from / to host memory (pageable is fine).  Default schedule: up to three pairs in flight on
+ * internal peer engines, images and maps staged through page-locked buffers.  SGM_OPT_SCHEDULE = 2: chained groups as in
+ * sgm_pipeline_batch_device with two groups in flight -- uploads of the next and downloads of the previous group run
+ * beside the kernels of the current one */
 int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t *rights, int H,
                       int W, int16_t *disps_out /* N*H*W */, float *xyz_out /* N*H*W*3 or NULL */,
                       const double *Q16 /* needed iff xyz_out */);
@@ -173,25 +179,45 @@ int sgm_valid_mask_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f
 int sgm_compact_points_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f32,
                               const void *d_colors_rgb, int64_t n, void *d_out_points,
                               void *d_out_colors, int64_t *n_valid);
-/* cell c13 in one call: disparity (int16) -> float disparity -> XYZ; any output may be NULL */
+/* the same without a host round trip: the count is written to *d_n_valid_i64 (an int64 in DEVICE memory) in stream order and
+ * nothing is synchronised -- the form the sharded pipeline uses (counts and points travel to rank 0 behind an event).
+ * Rows of d_out_points past the count are left as they were. */
+int sgm_compact_points_device_async(sgm_engine *e, const void *d_xyz, const void *d_disp_f32,
+                                    const void *d_colors_rgb, int64_t n, void *d_out_points,
+                                    void *d_out_colors, void *d_n_valid_i64);
 int sgm_init_undistort_rectify_map_device(sgm_engine *e, const double K[9], const double *dist, int ndist,
                                           const double *R, const double *P, int pcols, int W, int H,
                                           void *d_map1_f32, void *d_map2_f32);
 int sgm_remap_linear_u8_device(sgm_engine *e, const void *d_src, int sH, int sW, int64_t sstride, int cn,
                                const void *d_map1_f32, const void *d_map2_f32, int dH, int dW, void *d_dst,
                                int64_t dstride);
+/* cell c13 in one call: disparity (int16) -> float disparity -> XYZ; any output may be NULL */
 int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, int H, int W,
                         int64_t stride_bytes, const double Q[16], void *d_disp_i16,
                         void *d_disp_f32, void *d_xyz_f32);
 /* The driver cell over N resident pairs (BASELINE config 4: a batch of pairs per GPU; main.ipynb:780-797 once per pair),
  * throughput mode: arrays of N device pointers (d_disp_f32 / d_xyz_f32 may be NULL).  With SGM_OPT_SCHEDULE = 2 the
- * pairs share ONE chained sweep launch per pass (groups of up to 64 pairs on internal engines: about 13 GB of device
- * memory per 4K D=256 pair of a group); otherwise pair after pair.  Results equal N calls of sgm_pipeline_device.
- * Asynchronous: sgm_synchronize(e) waits for all of it. */
+ * pairs share ONE chained sweep launch per pass, in groups on internal engines (about 9 GB of device memory per 4K D=256
+ * pair of a group): a group is as large as device memory allows beside a reserve (at most 64 pairs, or
+ * SGM_OPT_GROUP_MAX), and a batch larger than that is cut into groups of equal size; configurations the chained sweeps do
+ * not cover (D <= 32, a single band) and other schedules run pair after pair.  Results equal N calls of
+ * sgm_pipeline_device; sgm_get_headroom afterwards covers every pair of the call.  Asynchronous: sgm_synchronize(e)
+ * waits for all of it.  An error return leaves nothing in flight (every internal stream is drained first) and the engine
+ * usable.  sgm_trim(e) gives the internal engines' memory back. */
 int sgm_pipeline_batch_device(sgm_engine *e, int N, const void *const *d_left, const void *const *d_right, int H, int W,
                               int64_t stride_bytes, const double Q[16], void *const *d_disp_i16,
                               void *const *d_disp_f32, void *const *d_xyz_f32);
+/* blocks until everything enqueued on the engine's stream is done; reports (once) a chained sweep that gave up, see sgm_check */
 int sgm_synchronize(sgm_engine *e);
+/* Status of the engine WITHOUT waiting for its stream, for callers that order the stream with events of their own
+ * (stream-ordered pipelines): SGM_ERR_HIP if a workgroup of a chained sweep (schedule 2) gave up waiting for the band
+ * above it since the last check -- a bounded wait that cannot end in a healthy launch (kernels_sweep.h: ChainWait); the
+ * results computed since the last check are then invalid.  The condition is reported once and cleared: the engine stays
+ * usable.  sgm_synchronize, sgm_compute, sgm_compute_batch, sgm_get_tap and sgm_trim report it as well. */
+int sgm_check(sgm_engine *e);
+/* destroys the internal engines a batch entry created (and their device memory) and the page-locked staging buffers;
+ * the engine's own buffers stay.  Blocks until the engine's stream is idle. */
+int sgm_trim(sgm_engine *e);
 
 /* per-stage HIP-event timing of the last compute (requires SGM_OPT_PROFILE = 1) */
 int sgm_get_stage_times(sgm_engine *e, sgm_stage_times *out);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SGM_HIP_LIB") or os.path.join(_HERE, "csrc", "libsgm_
 
 SGM_OK = 0
 SGM_TAP_COST, SGM_TAP_AGGR, SGM_TAP_DISP_RAW, SGM_TAP_DISP_MEDIAN = 0, 1, 2, 3
-SGM_OPT_KEEP_AGGR, SGM_OPT_PROFILE, SGM_OPT_SCHEDULE, SGM_OPT_SWEEP_ROWS, SGM_OPT_PREPASS_ROWS, SGM_OPT_CHAIN_WGS = 0, 1, 2, 3, 5, 6
+SGM_OPT_KEEP_AGGR, SGM_OPT_PROFILE, SGM_OPT_SCHEDULE, SGM_OPT_SWEEP_ROWS, SGM_OPT_PREPASS_ROWS, SGM_OPT_CHAIN_WGS, SGM_OPT_GROUP_MAX = 0, 1, 2, 3, 5, 6, 7
 SGM_OPT_DEBUG = 4    # csrc/sgm_debug.h: A/B switches for tools/ and tests/, not part of the public interface
 SGM_MAX_STAGES = 32
 
@@ -23,7 +23,7 @@ EXPORTS = (
     "sgm_abi_version", "sgm_device_count", "sgm_last_error", "sgm_create", "sgm_destroy",
     "sgm_set_option", "sgm_geometry", "sgm_compute", "sgm_compute_batch", "sgm_disp_to_float",
     "sgm_reproject", "sgm_valid_mask", "sgm_get_tap", "sgm_get_headroom", "sgm_median3x3", "sgm_filter_speckles", "sgm_compact_points",
-    "sgm_compact_points_device", "sgm_compute_device",
+    "sgm_compact_points_device", "sgm_compact_points_device_async", "sgm_compute_device", "sgm_check", "sgm_trim",
     "sgm_disp_to_float_device", "sgm_reproject_device", "sgm_valid_mask_device",
     "sgm_pipeline_device", "sgm_pipeline_batch_device", "sgm_synchronize", "sgm_get_stage_times", "sgm_algorithmic_bytes",
     "sgm_init_undistort_rectify_map", "sgm_init_undistort_rectify_map_device",
@@ -46,7 +46,7 @@ class LibraryMissing(RuntimeError):
     pass
 
 
-ABI_VERSION = 3   # include/sgm_hip.h: SGM_ABI_VERSION this binding was written against
+ABI_VERSION = 4   # include/sgm_hip.h: SGM_ABI_VERSION this binding was written against
 
 
 _lib = None
@@ -88,6 +88,9 @@ def load():
     L.sgm_filter_speckles.argtypes = [vp, vp, i32, i32, i32, i32, i32]
     L.sgm_compact_points.argtypes = [vp, vp, vp, vp, i64, vp, vp, C.POINTER(i64)]
     L.sgm_compact_points_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, C.POINTER(i64)]
+    L.sgm_compact_points_device_async.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
+    L.sgm_check.argtypes = [vp]
+    L.sgm_trim.argtypes = [vp]
     L.sgm_compute_device.argtypes = [vp, vp, vp, i32, i32, i64, vp]
     L.sgm_disp_to_float_device.argtypes = [vp, vp, i64, vp]
     L.sgm_reproject_device.argtypes = [vp, vp, i32, i32, vp, i32, vp]

@@ -597,4 +597,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(const float *__restrict
     }
 }
 
+// the total of a compaction (counts[m] after k_compact_scan) as the int64 the caller's device memory holds
+__global__ void k_compact_total(const uint32_t *__restrict__ total, int64_t *__restrict__ out) { *out = (int64_t)*total; }
+
 }  // namespace sgm

@@ -40,7 +40,7 @@ struct SweepArgs {
     uint32_t *ctl;   // [0] ticket, [1 + f * nbands + b] = pixels of the last row of band b of frame f that have reached HBM;
                      // zeroed before every launch
     uint32_t *prog;  // (set by the kernel) progress words of the frame a workgroup is working on = ctl + 1 + f * nbands
-    uint32_t *err;   // sticky, never reset by a launch: set when a bounded wait gave up
+    uint32_t *err;   // set when a bounded wait gave up; stays set until the host has reported it (sgm_engine.hip: check_chain)
     int nbands;
 };
 
@@ -117,8 +117,14 @@ __device__ __forceinline__ void sweep_write_start_state(uint32_t *ring, int slot
 // ("sc1": served behind this CU's L1), the payload is then read with sc1 loads as well
 // (cdna_hip_programming.md Guideline 16, R1 with the measured sc1-load form: one lane of the producer
 // stores the flag after its wave's payload stores are complete, the polling wave loads after its poll
-// has matched).  Every wait is bounded: after about 0.25 s it gives up, raises *err and lets the band
-// run on (its results are then wrong and the host reports SGM_ERR_HIP) -- the grid always drains.
+// has matched).  Every wait is bounded: after CHAIN_GIVE_UP polls in a row that saw the word stand still it
+// gives up, raises *err and lets the band run on (its results are then wrong and the host reports SGM_ERR_HIP
+// at its next check: sgm_synchronize / sgm_check) -- the grid always drains.  The bound counts this wave's OWN
+// polls (each a load that goes to L2 or HBM plus s_sleep: about a microsecond), not wall time: a queue that the
+// hardware scheduler parks for a while (several processes time-slicing one GPU, a debugger) parks producer and
+// consumer together and must not run the clock down, and a producer that still advances -- however slowly --
+// restarts the count.
+constexpr uint32_t CHAIN_GIVE_UP = 1u << 20;
 struct ChainWait {
     const uint32_t *word = nullptr;  // progress word of the band above (nullptr: nothing to wait for)
     uint32_t *err = nullptr;
@@ -140,12 +146,15 @@ struct ChainWait {
     __device__ __forceinline__ void until(uint32_t need)
     {
         if (seen >= need) return;
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        uint32_t idle = 0, last = seen;
         for (;;) {
             seen = peek();
             if (seen >= need) break;
             __builtin_amdgcn_s_sleep(8);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) {
+            if (seen != last) {  // the band above is alive
+                last = seen;
+                idle = 0;
+            } else if (++idle > CHAIN_GIVE_UP) {
                 if (lane_id() == 0) atomicOr(err, 1u);
                 seen = 0x7fffffffu;  // this workgroup stops waiting for good
                 break;

@@ -48,30 +48,111 @@ static int set_err(int code, const char *fmt, ...)
     } while (0)
 
 // ---- engine --------------------------------------------------------------------------------
+// Guarded allocation mode (environment SGM_DEBUG_ALLOC=1, read once per process; tests/test_gpu_guard.py runs parity
+// cases under it in a child process).  Every device buffer of an engine is then placed through the HIP virtual-memory
+// calls so that
+//   * it ENDS exactly at the end of its mapping (sizes that are no multiple of 16 bytes: up to 15 bytes earlier) and the
+//     pages behind -- and in front of -- the mapping are reserved but never mapped: a read or write past the buffer is a
+//     GPU memory access fault at once instead of a silent touch of a neighbouring allocation.  Scalar loads (k_pix's
+//     left-pixel records) and flat / global accesses carry no bounds check, unlike the buffer-descriptor accesses;
+//   * the low half of every address inside the buffer has bit 31 SET: a 64-bit pointer put together from two 32-bit
+//     halves with a signed low half (the int that __builtin_amdgcn_readfirstlane returns) turns into 0xffffffff'xxxxxxxx
+//     there -- the cause of round 3's memory access fault, DESIGN.md 4.6 -- while hipMalloc hands out such addresses
+//     only now and then.
+// Buffers above 1 GiB keep plain hipMalloc (the tests that use the mode run small frames).
+static int debug_alloc_mode()
+{
+    static const int m = [] {
+        const char *s = getenv("SGM_DEBUG_ALLOC");
+        return s ? atoi(s) : 0;
+    }();
+    return m;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // guarded mode only: the address range reserved, the part of it that is mapped, the physical allocation
+    void *va = nullptr, *map = nullptr;
+    size_t va_bytes = 0, map_bytes = 0;
+    hipMemGenericAllocationHandle_t handle{};
+    bool guarded = false;
+
+    int ensure_guarded(size_t bytes)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return set_err(SGM_ERR_HIP, "hipGetDevice failed");
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0)
+            return set_err(SGM_ERR_HIP, "SGM_DEBUG_ALLOC: hipMemGetAllocationGranularity failed");
+        const size_t G4 = (size_t)1 << 32;
+        const size_t mb = (bytes + gran - 1) / gran * gran;   // mapped bytes: whole granules
+        // room for a 4 GiB boundary with the mapping right below it and one unmapped granule on either side
+        const size_t vb = mb + G4 + 2 * gran;
+        void *r = nullptr;
+        if (hipMemAddressReserve(&r, vb, gran, nullptr, 0) != hipSuccess)
+            return set_err(SGM_ERR_NOMEM, "SGM_DEBUG_ALLOC: hipMemAddressReserve(%zu) failed", vb);
+        const uintptr_t r0 = (uintptr_t)r;
+        const uintptr_t m1 = (r0 + gran + mb + G4 - 1) / G4 * G4;   // first 4 GiB boundary with room for guard + mapping below it
+        const uintptr_t m0 = m1 - mb;                               // low halves of [m0, m1): [2^32 - mb, 2^32), bit 31 set (mb <= 2 GiB)
+        hipMemGenericAllocationHandle_t h{};
+        if (m0 < r0 + gran || m1 + gran > r0 + vb || hipMemCreate(&h, mb, &prop, 0) != hipSuccess) {
+            (void)hipMemAddressFree(r, vb);
+            return set_err(SGM_ERR_NOMEM, "SGM_DEBUG_ALLOC: hipMemCreate(%zu) failed", mb);
+        }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemMap((void *)m0, mb, 0, h, 0) != hipSuccess || hipMemSetAccess((void *)m0, mb, &acc, 1) != hipSuccess) {
+            (void)hipMemRelease(h);
+            (void)hipMemAddressFree(r, vb);
+            return set_err(SGM_ERR_HIP, "SGM_DEBUG_ALLOC: hipMemMap / hipMemSetAccess failed");
+        }
+        va = r;
+        va_bytes = vb;
+        map = (void *)m0;
+        map_bytes = mb;
+        handle = h;
+        guarded = true;
+        p = (void *)((m1 - bytes) & ~(uintptr_t)15);   // the buffer ends where the mapping ends (16-byte aligned start)
+        cap = bytes;
+        return SGM_OK;
+    }
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return SGM_OK;
         if (p) {
-            if (hipFree(p) != hipSuccess) return SGM_ERR_HIP;
-            p = nullptr;
-            cap = 0;
+            if (release() != hipSuccess) return SGM_ERR_HIP;
         }
+        if (debug_alloc_mode() && bytes <= ((size_t)1 << 30)) return ensure_guarded(bytes);
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
+            p = nullptr;
             set_err(SGM_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
             return SGM_ERR_NOMEM;
         }
         cap = bytes;
         return SGM_OK;
     }
-    void release()
+    hipError_t release()
     {
-        if (p) (void)hipFree(p);
+        hipError_t e = hipSuccess;
+        if (guarded) {
+            e = hipMemUnmap(map, map_bytes);
+            (void)hipMemRelease(handle);
+            (void)hipMemAddressFree(va, va_bytes);
+            guarded = false;
+            va = map = nullptr;
+        } else if (p) {
+            e = hipFree(p);
+        }
         p = nullptr;
         cap = 0;
+        return e;
     }
 };
 
@@ -122,6 +203,16 @@ struct sgm_engine {
     // buffers), each with page-locked staging buffers for the images and the disparity map
     sgm_engine *peer = nullptr, *peer2 = nullptr;
     std::vector<sgm_engine *> group;      // sgm_pipeline_batch_device: the other engines of a chained group (own streams and buffers)
+    int last_group = 0;                   // engines of `group` the last batch call used (sgm_get_headroom looks at all of them)
+    bool hr_accumulate = false;           // batch calls: the headroom record of this engine is NOT reset by the next compute (it then covers every pair the engine ran in the call)
+    int group_max = 0;                    // SGM_OPT_GROUP_MAX: pairs per chained launch (0 = as many as fit in memory, up to CHAIN_MAX_FRAMES)
+    // sgm_compute_batch, throughput mode: two groups in flight (the transfers of group g + 1 / g - 1 beside the kernels of
+    // group g).  Each engine of a group keeps the device images of ITS pair twice -- slot g & 1: left, right, int16 map,
+    // float map, XYZ -- with an event behind the upload and one behind the pair's last kernel; the engine the caller
+    // holds owns the two copy streams.
+    DevBuf io[2][5];
+    hipEvent_t ev_io_in[2] = {nullptr, nullptr}, ev_io_out[2] = {nullptr, nullptr};
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
     hipEvent_t ev_group = nullptr;
     HostBuf pin_left, pin_right, pin_disp;
     hipEvent_t ev_done = nullptr;
@@ -415,6 +506,50 @@ static int sweep_rows_for(const Geom &g, int override_rows, int npass, bool chai
     return std::max(1, std::min(R, maxR));
 }
 
+// ---- the schedule of one compute, decided from the geometry and the engine's options alone ----------------
+// (run_compute follows it; the batch entries read it BEFORE anything is allocated or enqueued: whether a configuration
+// runs chained, and what a pair costs in device memory)
+struct Plan {
+    bool byte_cost;   // per-pixel cost as bytes + k_box_u8 (else the int16 pipeline k_hsum + k_vsum*)
+    int GWs;          // lane-group width of the small-D kernels (64: none)
+    bool rows4;       // small-D schedule (D <= 64 outside throughput mode, D <= 32 always)
+    bool chain;       // chained sweeps (schedule 2)
+    int npass, R, nbands;
+};
+static Plan make_plan(const sgm_engine *e, const Geom &g, int H)
+{
+    Plan p;
+    // Byte pipeline (default): k_pix writes the per-pixel cost as uint8, k_box_u8 does the whole box
+    // filter from it.  Needs a window radius 1..5 (instantiations), a cost that fits a byte, and a
+    // pix volume below the 2 GiB a buffer descriptor spans here.  D <= 64: k_box_u8 in lane groups (several columns'
+    // disparities side by side in a wave); the per-pixel cost comes from k_pix_px (D <= 32, one thread per pixel) or
+    // k_pix (D = 48, 64: half its lanes idle, still less than the int16 pipeline's 3 V more traffic).
+    // debug 256: the int16 pipeline always; debug 4 (no lane groups): the int16 pipeline for D <= 64.
+    p.byte_cost = !(e->debug & 256) && (g.D > 64 || !(e->debug & 4)) && g.SW2 >= 1 && g.SW2 <= 5 && g.SH2 == g.SW2 &&
+                  2 * g.ftzero + 63 <= 255 && (int64_t)H * g.rowsz < (int64_t)0x7ff00000;
+    // D <= 32: rows without hand-off: band height 1, the pre-pass stores every row's
+    // state; needs the 3-volume state buffer below the 4 GiB a 32-bit buffer offset reaches.
+    // (At D = 64 the fused sweep is still ahead: 720p 0.35 against 0.39 ms, and 3 V of state.)
+    p.GWs = (e->debug & 4) ? 64 : group_width(g, H);
+    // Throughput mode (schedule 2) takes D = 48 .. 64 through the chained sweeps all the same (half the lanes idle, but
+    // 7 V of traffic per pair instead of the 22 V of the per-row state: batches of small frames are bound by HBM --
+    // 64 pairs 720p D=64: 0.38 against 0.55 ms per pair); D <= 32 keeps the small-D kernels in every mode.
+    p.rows4 = p.GWs <= 32 && e->sweep_rows <= 0 && !(e->schedule == 2 && p.GWs == 32) &&
+              (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
+    p.npass = g.mode == 1 ? 2 : 1;
+    // Chained schedule (SGM_OPT_SCHEDULE 2, kernels_sweep.h: k_sweep_chain): no pre-pass; the bands of a sweep hand the
+    // state of their last row to each other.  Only where the fused sweep runs (the small-D schedule keeps its own
+    // kernels), where there is more than one band, and not with debug 2 (winner-take-all inside the second sweep).
+    p.chain = e->schedule == 2 && !p.rows4 && !((e->debug & 2) && g.mode == 1) && g.W1 > 0;
+    p.R = p.rows4 ? 1 : sweep_rows_for(g, e->sweep_rows, p.npass, p.chain);
+    if (p.chain && (H + p.R - 1) / p.R <= 1) {
+        p.chain = false;
+        p.R = sweep_rows_for(g, e->sweep_rows, p.npass, false);
+    }
+    p.nbands = (H + p.R - 1) / p.R;
+    return p;
+}
+
 // ---- the matcher on device buffers ---------------------------------------------------------
 static int ensure_buffers(sgm_engine *e, int H, int W)
 {
@@ -426,10 +561,18 @@ static int ensure_buffers(sgm_engine *e, int H, int W)
     e->W = W;
     const size_t npx = (size_t)H * W;
     const size_t vol = (size_t)std::max<int64_t>(g.rowsz, 0) * H * sizeof(int16_t);
-    if ((rc = e->lrec.ensure(npx * 8))) return rc;
+    // 64 bytes of slack behind the last record: k_pix reads the records with scalar loads -- no bounds check, and the
+    // compiler may merge or widen them (the widest scalar load is 64 bytes).  Every load STARTS at a record of the
+    // frame, so none can leave the allocation.  (Not in the guarded mode: there the buffer ends where its mapping
+    // ends, and the parity cases of tests/test_gpu_guard.py show that no load goes past the last record at all.)
+    if ((rc = e->lrec.ensure(npx * 8 + (debug_alloc_mode() ? 0 : 64)))) return rc;
     if ((rc = e->rplanes.ensure(npx * 6))) return rc;
     if (vol) {
-        if ((rc = e->hsum.ensure(vol))) return rc;
+        // The byte pipeline keeps its per-pixel costs (V / 2) in the S buffer: they are dead when the block cost C is
+        // complete, and no kernel writes S before that (the sweeps, the in-row paths and k_paths5_g all read C; in a batch
+        // every pair's cost stage is complete before the joint sweep launch starts).  Only the int16 pipeline needs a
+        // volume of its own for the horizontal sums.  4K D=256: 13 -> 9 GB per engine (round 3 allocated V for them always).
+        if (!make_plan(e, g, H).byte_cost && (rc = e->hsum.ensure(vol))) return rc;
         if ((rc = e->cost.ensure(vol))) return rc;
         if ((rc = e->aggr.ensure(vol))) return rc;
     }
@@ -493,7 +636,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
     const unsigned nb_px = (unsigned)((npx + 255) / 256);
 
     int16_t *raw = (int16_t *)e->disp_raw.p, *med = (int16_t *)e->disp_med.p;
-    if (do_pre) HIP_TRY(hipMemsetAsync(e->headroom.p, 0, 8, st));  // headroom record of this compute (sgm_get_headroom)
+    if (do_pre && !e->hr_accumulate) HIP_TRY(hipMemsetAsync(e->headroom.p, 0, 8, st));  // headroom record of this compute (sgm_get_headroom)
 
     if (g.W1 <= 0) {
         // no column can be matched: the whole map is invalid (upstream early-out), then median
@@ -576,14 +719,8 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             default: break;
             }
         };
-        // Byte pipeline (default): k_pix writes the per-pixel cost as uint8, k_box_u8 does the whole box
-        // filter from it.  Needs a window radius 1..5 (instantiations), a cost that fits a byte, and a
-        // pix volume below the 2 GiB a buffer descriptor spans here.  D <= 64: k_box_u8 in lane groups (several columns'
-        // disparities side by side in a wave); the per-pixel cost comes from k_pix_px (D <= 32, one thread per pixel) or
-        // k_pix (D = 48, 64: half its lanes idle, still less than the int16 pipeline's 3 V more traffic).
-        // debug 256: the int16 pipeline always; debug 4 (no lane groups): the int16 pipeline for D <= 64.
-        const bool byte_cost = !(e->debug & 256) && (g.D > 64 || !(e->debug & 4)) && g.SW2 >= 1 && g.SW2 <= 5 && g.SH2 == g.SW2 &&
-                               2 * g.ftzero + 63 <= 255 && (int64_t)H * g.rowsz < (int64_t)0x7ff00000;
+        const Plan plan = make_plan(e, g, H);   // (the same decisions the batch entries read before they enqueue anything)
+        const bool byte_cost = plan.byte_cost;
         const int GWc = g.D > 64 ? 64 : (g.D <= 16 ? 8 : (g.D <= 32 ? 16 : 32));  // lane-group width of k_box_u8
         const int cpw = 16 * (64 / GWc);  // columns per workgroup of k_box_u8: 4 waves x (64 / GW groups) x 4 columns
         // rows per band of k_box_u8 (a band re-reads 2 * SH2 rows above it; multiples of 16: the register rings): 96, less
@@ -599,7 +736,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             const int seg_l = (nj + 128 * g.NP + 15) & ~15;
             const size_t lds = (size_t)lrec_b + 6 * (size_t)seg_l;
             dim3 grid((unsigned)((int64_t)(y_hi - y_lo) * nchunks)), block(64);
-            uint8_t *px = (uint8_t *)HS;
+            uint8_t *px = (uint8_t *)e->aggr.p;   // (the byte costs live in the S buffer until C is complete: ensure_buffers)
             if (g.D <= 32) {  // one thread per pixel (whole frame; callers pass [0, H))
                 dim3 gridp((g.W1 + 255) / 256, H), blockp(256);
                 hipLaunchKernelGGL(k_pix_px, gridp, blockp, (size_t)6 * (256 + g.D), on, g, lrec, rpl, px);
@@ -610,7 +747,7 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
         };
         auto launch_box = [&](int nb, hipStream_t on) {
             dim3 grid((g.W1 + cpw - 1) / cpw, nb), block(256);
-            const uint8_t *px = (const uint8_t *)HS;
+            const uint8_t *px = (const uint8_t *)e->aggr.p;
             int16_t *cp2 = (int16_t *)e->cost.p;
 #define SGM_BOX(R_)                                                                                        \
     case R_:                                                                                               \
@@ -631,27 +768,13 @@ static int run_compute(sgm_engine *e, const uint8_t *d_left, const uint8_t *d_ri
             }
 #undef SGM_BOX
         };
-        // ---- schedule parameters (needed before the cost stage: the first pass may be pipelined with it)
-        // D <= 32: rows without hand-off (k_rows4_g): band height 1, the pre-pass stores every row's
-        // state; needs the 3-volume state buffer below the 4 GiB a 32-bit buffer offset reaches.
-        // (At D = 64 the fused sweep is still ahead: 720p 0.35 against 0.39 ms, and 3 V of state.)
-        const int GWs = (e->debug & 4) ? 64 : group_width(g, H);
-        // Throughput mode (schedule 2) takes D = 48 .. 64 through the chained sweeps all the same (half the lanes idle, but
-        // 7 V of traffic per pair instead of the 22 V of the per-row state: batches of small frames are bound by HBM --
-        // 64 pairs 720p D=64: 0.38 against 0.55 ms per pair); D <= 32 keeps the small-D kernels in every mode.
-        const bool rows4 = GWs <= 32 && e->sweep_rows <= 0 && !(e->schedule == 2 && GWs == 32) &&
-                           (int64_t)H * g.rowsz * 2 * 3 < (int64_t)0xfff00000;
-        const int npass = g.mode == 1 ? 2 : 1;
-        // Chained schedule (SGM_OPT_SCHEDULE 2, kernels_sweep.h: k_sweep_chain): no pre-pass; the bands of a sweep hand the
-        // state of their last row to each other.  Only where the fused sweep runs (the small-D schedule keeps its own
-        // kernels), where there is more than one band, and not with debug 2 (winner-take-all inside the second sweep).
-        bool chain = e->schedule == 2 && !rows4 && !((e->debug & 2) && g.mode == 1);
-        int R = rows4 ? 1 : sweep_rows_for(g, e->sweep_rows, npass, chain);
-        if (chain && (H + R - 1) / R <= 1) {
-            chain = false;
-            R = sweep_rows_for(g, e->sweep_rows, npass, false);
-        }
-        const int nbands = (H + R - 1) / R;
+        // ---- schedule parameters (make_plan)
+        const int GWs = plan.GWs;
+        const bool rows4 = plan.rows4;
+        const int npass = plan.npass;
+        const bool chain = plan.chain;
+        const int R = plan.R;
+        const int nbands = plan.nbands;
         // Narrow frames (fewer than ~1.5 lines per SIMD) are bound by the latency of one wave's
         // instruction stream: there the single-direction kernel with one wave per (line, role) -- three
         // times the waves, a third of the work each -- is faster (720p D=64: 0.26 against 0.34 ms); its
@@ -1226,16 +1349,35 @@ int sgm_create(const sgm_params *params, int device_id, void *stream, sgm_engine
     return SGM_OK;
 }
 
+// every device buffer of an engine (the engine stays usable: buffers come back on the next call that needs them)
+static void release_buffers(sgm_engine *e)
+{
+    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->aggr2, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2, &e->pstate, &e->pstate2,
+                      &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
+                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom, &e->chain_ctl, &e->chain_err, &e->aggr3, &e->aggr4, &e->aggr5};
+    for (DevBuf *b : bufs) (void)b->release();
+    for (auto &slot : e->io)
+        for (DevBuf &b : slot) (void)b.release();
+    e->g.hr = nullptr;
+}
+
 void sgm_destroy(sgm_engine *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_left, &e->in_right, &e->lrec, &e->rplanes, &e->hsum, &e->cost, &e->aggr, &e->aggr2, &e->rmap1, &e->rmap2, &e->rsrc, &e->rdst, &e->wta, &e->bndL, &e->bndL2, &e->pstate, &e->pstate2,
-                      &e->disp_raw, &e->disp_med, &e->disp_out, &e->label, &e->csize, &e->rlen, &e->f32, &e->xyz, &e->mask,
-                      &e->minkey, &e->ccount, &e->cpts, &e->crgb, &e->crgb_in, &e->headroom, &e->chain_ctl, &e->chain_err, &e->aggr3, &e->aggr4, &e->aggr5};
-    for (DevBuf *b : bufs) b->release();
+    if (e->copy_in) {
+        (void)hipStreamSynchronize(e->copy_in);
+        (void)hipStreamDestroy(e->copy_in);
+    }
+    if (e->copy_out) {
+        (void)hipStreamSynchronize(e->copy_out);
+        (void)hipStreamDestroy(e->copy_out);
+    }
+    release_buffers(e);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->ev_io_in) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->ev_io_out) if (ev) (void)hipEventDestroy(ev);
     if (e->aux2) {
         (void)hipStreamSynchronize(e->aux2);
         (void)hipEventDestroy(e->ev_join2);
@@ -1274,18 +1416,25 @@ int sgm_set_option(sgm_engine *e, int option, int value)
         e->debug = value;
     }
     else if (option == SGM_OPT_PREPASS_ROWS) e->prepass_rows = std::max(0, value);
+    else if (option == SGM_OPT_GROUP_MAX) e->group_max = std::max(0, std::min(value, CHAIN_MAX_FRAMES));
     else return set_err(SGM_ERR_INVALID_ARG, "unknown option %d", option);
     return SGM_OK;
 }
 
 // Chained sweeps bound every wait for another workgroup (kernels_sweep.h: ChainWait); a wait that gave up leaves a
-// sticky flag and wrong results.  Looked at wherever the host synchronises with the engine's stream anyway.
+// flag beside the control words and wrong results in whatever was computed since the last check.  The flag is looked at
+// wherever the host synchronises with the engine's stream anyway, and by sgm_check for callers that order the engine's
+// stream with events of their own (dist.IngestPipeline, bench.py); once reported it is cleared, so that the engine is
+// usable again (the next launch zeroes its control words as every launch does).
 static int check_chain(sgm_engine *e)
 {
     if (!e->chain_err.p) return SGM_OK;
     uint32_t f = 0;
     HIP_TRY(hipMemcpy(&f, e->chain_err.p, 4, hipMemcpyDeviceToHost));
-    if (f) return set_err(SGM_ERR_HIP, "chained sweep: a workgroup gave up waiting for the band above it (results are invalid)");
+    if (f) {
+        HIP_TRY(hipMemset(e->chain_err.p, 0, 4));
+        return set_err(SGM_ERR_HIP, "chained sweep: a workgroup gave up waiting for the band above it (results since the last check are invalid)");
+    }
     return SGM_OK;
 }
 
@@ -1294,6 +1443,32 @@ int sgm_synchronize(sgm_engine *e)
     if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return check_chain(e);
+}
+
+int sgm_check(sgm_engine *e)
+{
+    if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
+    HIP_TRY(hipSetDevice(e->device));
+    return check_chain(e);
+}
+
+// gives back what the engine can build again: the internal engines of sgm_pipeline_batch_device / sgm_compute_batch (a
+// group of 4K D=256 pairs holds about 9 GB per pair) and the page-locked staging buffers
+int sgm_trim(sgm_engine *e)
+{
+    if (!e) return set_err(SGM_ERR_INVALID_ARG, "engine is null");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (sgm_engine *q : e->group) sgm_destroy(q);
+    e->group.clear();
+    e->last_group = 0;
+    if (e->peer) sgm_destroy(e->peer);
+    if (e->peer2) sgm_destroy(e->peer2);
+    e->peer = e->peer2 = nullptr;
+    e->pin_left.release();
+    e->pin_right.release();
+    e->pin_disp.release();
     return check_chain(e);
 }
 
@@ -1461,125 +1636,232 @@ int sgm_pipeline_device(sgm_engine *e, const void *d_left, const void *d_right, 
     return run_float_xyz(e, di, H, W, Q, d_disp_f32, d_xyz_f32);
 }
 
-// N pairs resident in device memory, throughput mode.  With the chained schedule (SGM_OPT_SCHEDULE 2 on `e`) and a
-// configuration the fused sweeps cover, the pairs go through the frame in lockstep of its phases: cost stage of every pair
-// (each on the stream of one of up to CHAIN_MAX_FRAMES internal engines), then ONE chained sweep launch per pass over all
-// pairs of the group on `e`'s stream, then the winner-take-all and the epilogue of every pair.  One frame's chain of bands
-// keeps only about 50 workgroups busy; a group of 6 or more fills the GPU, and no boundary pre-pass runs at all.
-// Otherwise: pair after pair on `e` (the schedule `e` is set to).  Results equal N calls of sgm_pipeline_device.
+// ---- N pairs, throughput mode --------------------------------------------------------------------------------
+// With the chained schedule (SGM_OPT_SCHEDULE 2 on `e`) and a configuration the fused sweeps cover, the pairs go through
+// the frame in lockstep of its phases: cost stage of every pair (each on the stream of one of up to CHAIN_MAX_FRAMES
+// internal engines), then ONE chained sweep launch per pass over all pairs of the group on `e`'s stream, then the
+// winner-take-all and the epilogue of every pair.  One frame's chain of bands keeps only about 50 workgroups busy; a
+// group of 6 or more fills the GPU, and no boundary pre-pass runs at all.
+
+// Everything one pair of a chained group needs on its engine, allocated BEFORE anything is enqueued (so that running out
+// of memory costs nothing but a smaller group)
+static int prepare_pair_buffers(sgm_engine *q, int H, int W, const Plan &pl)
+{
+    int rc = ensure_buffers(q, H, W);
+    if (rc) return rc;
+    const Geom &g = q->g;
+    const size_t npx = (size_t)H * W;
+    if (pl.nbands > 1 && (rc = q->bndL.ensure((size_t)pl.nbands * g.W1 * 3 * g.D * 2))) return rc;
+    if (q->params.speckleRange >= 0 && q->params.speckleWindowSize > 0 &&
+        ((rc = q->label.ensure(npx * 4)) || (rc = q->csize.ensure(npx * 4)) || (rc = q->rlen.ensure(npx * 4))))
+        return rc;
+    const bool two_vol = g.mode == 0 && g.D <= 128 && !(q->debug & (4 | 2 | 65536));   // (run_compute: the fifth path's own volume)
+    if (two_vol && (rc = q->aggr2.ensure((size_t)g.rowsz * H * sizeof(int16_t)))) return rc;
+    return SGM_OK;
+}
+
+// The engines of a chained group for up to `want` pairs: e itself + internal engines, created, configured like e and
+// sized for the shape.  Fewer than `want` when device memory runs out (or would drop below a reserve of 1 GiB / 2 %:
+// the caller and the runtime need room too) -- a batch then simply takes more groups.  *n_out >= 1.
+static int prepare_group(sgm_engine *e, int want, int H, int W, const Plan &pl, int *n_out)
+{
+    int rc;
+    *n_out = 0;
+    if (e->group_max > 0) want = std::min(want, e->group_max);
+    want = std::max(1, std::min(want, CHAIN_MAX_FRAMES));
+    if ((rc = prepare_pair_buffers(e, H, W, pl))) return rc;
+    *n_out = 1;
+    if (want > 1 && !e->ev_group) HIP_TRY(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
+    for (int k = 1; k < want; k++) {
+        const bool is_new = (int)e->group.size() < k;
+        if (is_new) {
+            sgm_engine *q = nullptr;
+            if ((rc = sgm_create(&e->params, e->device, nullptr, &q))) return rc;
+            e->group.push_back(q);
+        }
+        sgm_engine *q = e->group[k - 1];
+        q->keep_aggr = 0;
+        q->profile = 0;
+        q->schedule = e->schedule;
+        q->sweep_rows = e->sweep_rows;
+        q->debug = e->debug;
+        q->chain_wgs = e->chain_wgs;
+        if (!q->ev_done) HIP_TRY(hipEventCreateWithFlags(&q->ev_done, hipEventDisableTiming));
+        const bool sized = q->H == H && q->W == W && q->cost.p;     // (ran this shape before: nothing to allocate)
+        rc = prepare_pair_buffers(q, H, W, pl);
+        size_t fr = 0, tot = 0;
+        if (!rc && !sized && hipMemGetInfo(&fr, &tot) == hipSuccess && fr < std::max<size_t>((size_t)1 << 30, tot / 50))
+            rc = SGM_ERR_NOMEM;
+        if (rc == SGM_ERR_NOMEM) {
+            release_buffers(q);   // (a half-sized engine would only hold memory the smaller group could use)
+            q->H = q->W = 0;
+            break;
+        }
+        if (rc) return rc;
+        *n_out = k + 1;
+    }
+    return SGM_OK;
+}
+
+// every stream a batch call may have work on is drained before an error is returned, and the engines get their
+// per-call flags back
+struct BatchGuard {
+    sgm_engine *e;
+    bool ok = false;
+    ~BatchGuard()
+    {
+        e->hr_accumulate = false;
+        for (sgm_engine *q : e->group) q->hr_accumulate = false;
+        if (ok) return;
+        (void)hipStreamSynchronize(e->stream);
+        for (sgm_engine *q : e->group) (void)hipStreamSynchronize(q->stream);
+        if (e->copy_in) (void)hipStreamSynchronize(e->copy_in);
+        if (e->copy_out) (void)hipStreamSynchronize(e->copy_out);
+    }
+};
+
+// One group (n >= 2 pairs on eng[0 .. n-1], eng[0] = e) through cost stages, joint sweeps, epilogues.  in_ready[k] (may be
+// null): an event pair k's cost stage waits for (its images have arrived); out_done[k] (may be null): recorded behind
+// pair k's last kernel.
+static int run_group(sgm_engine *e, sgm_engine *const *eng, int n, const Plan &pl, const void *const *d_left, const void *const *d_right,
+                     int H, int W, int64_t stride_bytes, const double Q[16], void *const *d_disp_i16, void *const *d_disp_f32,
+                     void *const *d_xyz_f32, const hipEvent_t *in_ready, const hipEvent_t *out_done)
+{
+    int rc;
+    // cost stage of every pair on the stream of its own engine, from where `e`'s stream stands now (the caller's
+    // inputs may have been produced on it).  Side by side rather than one after the other: the per-pixel cost
+    // kernel is bound by the vector units, the box filter by HBM -- pairs in different kernels overlap (12 pairs
+    // 4K D=256: 7.2 against 7.4 ms per pair with the cost stages in one stream).
+    HIP_TRY(hipEventRecord(e->ev_group, e->stream));
+    for (int k = 1; k < n; k++) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, e->ev_group, 0));
+    for (int k = 0; k < n; k++) {
+        if (in_ready && in_ready[k]) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, in_ready[k], 0));
+        if ((rc = run_compute(eng[k], (const uint8_t *)d_left[k], (const uint8_t *)d_right[k], H, W, stride_bytes,
+                              (int16_t *)d_disp_i16[k], PH_PRE)))
+            return rc;
+        if (!eng[k]->plan_chain) return set_err(SGM_ERR_HIP, "internal: a pair of a chained group did not plan a chained sweep");
+    }
+    // ---- the sweeps of all n pairs: one launch per pass on e's stream, behind every pair's cost stage
+    const Geom &g = e->g;
+    const int R = pl.R, nbands = pl.nbands, npass = pl.npass;
+    const size_t ctl_bytes = ((size_t)(1 + (size_t)n * nbands) * 4 + 15) & ~(size_t)15;
+    if ((rc = e->chain_ctl.ensure(ctl_bytes))) return rc;
+    for (int k = 1; k < n; k++) {
+        HIP_TRY(hipEventRecord(eng[k]->ev_done, eng[k]->stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream, eng[k]->ev_done, 0));
+    }
+    stage_break(e);
+    ChainFrames fr;
+    fr.nf = n;
+    for (int k = 0; k < n; k++) {
+        fr.C[k] = (const int16_t *)eng[k]->cost.p;
+        fr.S[k] = (int16_t *)eng[k]->aggr.p;
+        fr.bnd[k] = (int16_t *)eng[k]->bndL.p;
+        fr.hr[k] = eng[k]->g.hr;
+    }
+    for (int pass = 0; pass < npass; pass++) {
+        const int ydir = pass == 0 ? 1 : -1;
+        SweepArgs a{ydir, ydir, R, nullptr, nullptr, nullptr, nullptr, 0, e->debug, (uint32_t *)e->chain_ctl.p, nullptr,
+                    (uint32_t *)e->chain_err.p, nbands};
+        HIP_TRY(hipMemsetAsync(e->chain_ctl.p, 0, ctl_bytes, e->stream));
+        stage_break(e);
+        if ((rc = stage_begin(e, pass == 0 ? "chain_dn" : "chain_up"))) return rc;
+        if ((rc = launch_chain(g, a, fr, pass == 0 ? SWEEP_FIRST : SWEEP_ACCUM, chain_window(g, R, nbands, n, e->chain_wgs), e->stream)))
+            return rc;
+        KCHECK();
+        if ((rc = stage_end(e, 1))) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->ev_group, e->stream));
+    // ---- the rest of every pair on its own stream (memory-bound kernels of different pairs side by side)
+    for (int k = 0; k < n; k++) {
+        if (k > 0) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, e->ev_group, 0));
+        if ((rc = run_compute(eng[k], (const uint8_t *)d_left[k], (const uint8_t *)d_right[k], H, W, stride_bytes,
+                              (int16_t *)d_disp_i16[k], PH_POST)))
+            return rc;
+        if ((rc = run_float_xyz(eng[k], (const int16_t *)d_disp_i16[k], H, W, Q, d_disp_f32 ? d_disp_f32[k] : nullptr,
+                                d_xyz_f32 ? d_xyz_f32[k] : nullptr)))
+            return rc;
+        if (out_done && out_done[k]) HIP_TRY(hipEventRecord(out_done[k], eng[k]->stream));
+    }
+    // e's stream ends behind everything the group did
+    for (int k = 1; k < n; k++) {
+        HIP_TRY(hipEventRecord(eng[k]->ev_done, eng[k]->stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream, eng[k]->ev_done, 0));
+    }
+    stage_break(e);
+    return SGM_OK;
+}
+
+// can this call run chained, and with which plan ?  (decided from the geometry alone: nothing is created or enqueued)
+static int batch_plan(sgm_engine *e, int N, int H, int W, Plan *pl, bool *joint)
+{
+    if (H <= 0 || W < 2) return set_err(SGM_ERR_INVALID_ARG, "bad shape H=%d W=%d", H, W);
+    if (W > 32767 || H > 32767) return set_err(SGM_ERR_UNSUPPORTED, "image larger than 32767 in a dimension");
+    Geom g;
+    int rc = normalise(&e->params, H, W, &g);
+    if (rc) return rc;
+    *pl = make_plan(e, g, H);
+    *joint = e->schedule == 2 && N > 1 && pl->chain && e->group_max != 1;
+    return SGM_OK;
+}
+
+// N pairs resident in device memory.  Chained groups when the configuration allows (groups as large as device memory
+// holds, up to CHAIN_MAX_FRAMES or SGM_OPT_GROUP_MAX; a batch larger than a group is cut into groups of equal size);
+// otherwise pair after pair on `e` (the schedule `e` is set to).  Results equal N calls of sgm_pipeline_device.
 // Asynchronous like sgm_pipeline_device: returns when everything is enqueued; sgm_synchronize(e) waits for all of it.
+// On an error every stream of the group is drained before the call returns.
 int sgm_pipeline_batch_device(sgm_engine *e, int N, const void *const *d_left, const void *const *d_right, int H, int W,
                               int64_t stride_bytes, const double Q[16], void *const *d_disp_i16, void *const *d_disp_f32,
                               void *const *d_xyz_f32)
 {
     if (!e || N <= 0 || !d_left || !d_right || !d_disp_i16) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    for (int i = 0; i < N; i++)
+        if (!d_left[i] || !d_right[i] || !d_disp_i16[i]) return set_err(SGM_ERR_INVALID_ARG, "null pointer for pair %d", i);
+    if (stride_bytes < W) return set_err(SGM_ERR_INVALID_ARG, "bad shape H=%d W=%d stride=%lld", H, W, (long long)stride_bytes);
+    if (d_xyz_f32 && !Q) return set_err(SGM_ERR_INVALID_ARG, "Q is null");
     HIP_TRY(hipSetDevice(e->device));
     int rc;
-    // can this configuration run chained ?  (decided by the first pair's PH_PRE; the same for every pair of the batch)
-    bool joint = e->schedule == 2 && N > 1;
+    Plan pl;
+    bool joint = false;
+    if ((rc = batch_plan(e, N, H, W, &pl, &joint))) return rc;
+    BatchGuard guard{e};
+    e->last_group = 0;
+    int cap = 1;
     if (joint) {
-        while ((int)e->group.size() < std::min(N, CHAIN_MAX_FRAMES) - 1) {
-            sgm_engine *q = nullptr;
-            if ((rc = sgm_create(&e->params, e->device, nullptr, &q))) return rc;
-            e->group.push_back(q);
+        if ((rc = prepare_group(e, N, H, W, pl, &cap))) return rc;
+        if (!e->chain_err.p) {
+            if ((rc = e->chain_err.ensure(16))) return rc;
+            HIP_TRY(hipMemsetAsync(e->chain_err.p, 0, 16, e->stream));
         }
-        if (!e->ev_group) HIP_TRY(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
     }
-    for (int i0 = 0; i0 < N; i0 += CHAIN_MAX_FRAMES) {
-        const int n = std::min(N - i0, CHAIN_MAX_FRAMES);
-        std::vector<sgm_engine *> eng(n);
-        for (int k = 0; k < n; k++) {
-            sgm_engine *q = (k == 0 || !joint) ? e : e->group[k - 1];
-            eng[k] = q;
-            if (q != e) {
-                q->keep_aggr = 0;
-                q->profile = 0;
-                q->schedule = e->schedule;
-                q->sweep_rows = e->sweep_rows;
-                q->debug = e->debug;
-                q->chain_wgs = e->chain_wgs;
-                if (!q->ev_done) HIP_TRY(hipEventCreateWithFlags(&q->ev_done, hipEventDisableTiming));
-            }
+    if (!joint || cap < 2) {
+        for (int i = 0; i < N; i++) {
+            e->hr_accumulate = i > 0;     // (the headroom record of the call covers every pair)
+            if ((rc = sgm_pipeline_device(e, d_left[i], d_right[i], H, W, stride_bytes, Q, d_disp_i16[i],
+                                          d_disp_f32 ? d_disp_f32[i] : nullptr, d_xyz_f32 ? d_xyz_f32[i] : nullptr)))
+                return rc;
         }
-        if (joint && n > 1) {
-            // cost stage of every pair on the stream of its own engine, from where `e`'s stream stands now (the caller's
-            // inputs may have been produced on it).  Side by side rather than one after the other: the per-pixel cost
-            // kernel is bound by the vector units, the box filter by HBM -- pairs in different kernels overlap (12 pairs
-            // 4K D=256: 7.2 against 7.4 ms per pair with the cost stages in one stream).
-            HIP_TRY(hipEventRecord(e->ev_group, e->stream));
-            for (int k = 1; k < n; k++) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, e->ev_group, 0));
-            for (int k = 0; k < n && joint; k++) {
-                rc = run_compute(eng[k], (const uint8_t *)d_left[i0 + k], (const uint8_t *)d_right[i0 + k], H, W, stride_bytes,
-                                 (int16_t *)d_disp_i16[i0 + k], PH_PRE);
-                if (rc) {
-                    if (k == 0 && !e->plan_chain) {  // not a configuration for chained sweeps: nothing is enqueued yet but pair 0's cost stage
-                        joint = false;
-                        break;
-                    }
-                    return rc;
-                }
-            }
-        }
-        if (!joint || n == 1) {
-            joint = false;
-            for (int k = 0; k < n; k++) {
-                const int i = i0 + k;
-                if ((rc = sgm_pipeline_device(e, d_left[i], d_right[i], H, W, stride_bytes, Q, d_disp_i16[i],
-                                              d_disp_f32 ? d_disp_f32[i] : nullptr, d_xyz_f32 ? d_xyz_f32[i] : nullptr)))
-                    return rc;
-            }
+        guard.ok = true;
+        return SGM_OK;
+    }
+    const int ngroups = (N + cap - 1) / cap, per = (N + ngroups - 1) / ngroups;   // groups of equal size
+    e->last_group = std::min(per, N) - 1;
+    std::vector<sgm_engine *> eng(per);
+    for (int k = 0; k < per; k++) eng[k] = k == 0 ? e : e->group[k - 1];
+    for (int i0 = 0; i0 < N; i0 += per) {
+        const int n = std::min(N - i0, per);
+        for (int k = 0; k < n; k++) eng[k]->hr_accumulate = i0 > 0;
+        if (n == 1) {
+            if ((rc = sgm_pipeline_device(e, d_left[i0], d_right[i0], H, W, stride_bytes, Q, d_disp_i16[i0],
+                                          d_disp_f32 ? d_disp_f32[i0] : nullptr, d_xyz_f32 ? d_xyz_f32[i0] : nullptr)))
+                return rc;
             continue;
         }
-        // ---- the sweeps of all n pairs: one launch per pass on e's stream, behind every pair's cost stage
-        const Geom &g = e->g;
-        const int R = e->plan_R, nbands = e->plan_nbands, npass = g.mode == 1 ? 2 : 1;
-        const size_t ctl_bytes = ((size_t)(1 + (size_t)n * nbands) * 4 + 15) & ~(size_t)15;
-        if ((rc = e->chain_ctl.ensure(ctl_bytes))) return rc;
-        for (int k = 1; k < n; k++) {
-            HIP_TRY(hipEventRecord(eng[k]->ev_done, eng[k]->stream));
-            HIP_TRY(hipStreamWaitEvent(e->stream, eng[k]->ev_done, 0));
-        }
-        stage_break(e);
-        ChainFrames fr;
-        fr.nf = n;
-        for (int k = 0; k < n; k++) {
-            fr.C[k] = (const int16_t *)eng[k]->cost.p;
-            fr.S[k] = (int16_t *)eng[k]->aggr.p;
-            fr.bnd[k] = (int16_t *)eng[k]->bndL.p;
-            fr.hr[k] = eng[k]->g.hr;
-        }
-        for (int pass = 0; pass < npass; pass++) {
-            const int ydir = pass == 0 ? 1 : -1;
-            SweepArgs a{ydir, ydir, R, nullptr, nullptr, nullptr, nullptr, 0, e->debug, (uint32_t *)e->chain_ctl.p, nullptr,
-                        (uint32_t *)e->chain_err.p, nbands};
-            HIP_TRY(hipMemsetAsync(e->chain_ctl.p, 0, ctl_bytes, e->stream));
-            stage_break(e);
-            if ((rc = stage_begin(e, pass == 0 ? "chain_dn" : "chain_up"))) return rc;
-            if ((rc = launch_chain(g, a, fr, pass == 0 ? SWEEP_FIRST : SWEEP_ACCUM,
-                                   chain_window(g, R, nbands, n, e->chain_wgs), e->stream)))
-                return rc;
-            KCHECK();
-            if ((rc = stage_end(e, 1))) return rc;
-        }
-        HIP_TRY(hipEventRecord(e->ev_group, e->stream));
-        // ---- the rest of every pair on its own stream (memory-bound kernels of different pairs side by side)
-        for (int k = 0; k < n; k++) {
-            const int i = i0 + k;
-            if (k > 0) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, e->ev_group, 0));
-            if ((rc = run_compute(eng[k], (const uint8_t *)d_left[i], (const uint8_t *)d_right[i], H, W, stride_bytes,
-                                  (int16_t *)d_disp_i16[i], PH_POST)))
-                return rc;
-            if ((rc = run_float_xyz(eng[k], (const int16_t *)d_disp_i16[i], H, W, Q, d_disp_f32 ? d_disp_f32[i] : nullptr,
-                                    d_xyz_f32 ? d_xyz_f32[i] : nullptr)))
-                return rc;
-        }
-        // e's stream ends behind everything the group did
-        for (int k = 1; k < n; k++) {
-            HIP_TRY(hipEventRecord(eng[k]->ev_done, eng[k]->stream));
-            HIP_TRY(hipStreamWaitEvent(e->stream, eng[k]->ev_done, 0));
-        }
-        stage_break(e);
+        if ((rc = run_group(e, eng.data(), n, pl, d_left + i0, d_right + i0, H, W, stride_bytes, Q, d_disp_i16 + i0,
+                            d_disp_f32 ? d_disp_f32 + i0 : nullptr, d_xyz_f32 ? d_xyz_f32 + i0 : nullptr, nullptr, nullptr)))
+            return rc;
     }
+    guard.ok = true;
     return SGM_OK;
 }
 
@@ -1617,45 +1899,101 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
     HIP_TRY(hipSetDevice(e->device));
     const size_t npx = (size_t)H * W;
     int rc;
-    if (e->schedule == 2 && N > 1) {
-        // throughput mode: groups of up to 12 pairs through sgm_pipeline_batch_device (one chained sweep launch per pass
-        // and group); inputs and results of a group staged in device buffers of the group's engines
-        const int GN = 12;
-        std::vector<const void *> dl(GN), dr(GN);
-        std::vector<void *> dd(GN), df(GN), dx(GN);
-        for (int i0 = 0; i0 < N; i0 += GN) {
-            const int n = std::min(GN, N - i0);
-            while ((int)e->group.size() < n - 1) {
-                sgm_engine *q = nullptr;
-                if ((rc = sgm_create(&e->params, e->device, nullptr, &q))) return rc;
-                e->group.push_back(q);
+    Plan pl;
+    bool joint = false;
+    if ((rc = batch_plan(e, N, H, W, &pl, &joint))) return rc;
+    if (joint) {
+        // Throughput mode: chained groups as large as device memory holds, TWO groups in flight -- while the kernels of
+        // group g run, the images of group g + 1 are uploaded and the maps of group g - 1 downloaded on two copy streams
+        // of their own.  Every pair has its device images twice (slot g & 1) on the engine that runs it, an event behind
+        // its upload (its cost stage waits for that one only: the first kernels start when the first pair has arrived,
+        // not the whole group) and one behind its last kernel (its download waits for that one only).  The caller's
+        // memory is pageable: hipMemcpyAsync from / to it blocks the host for the length of the copy, which orders the
+        // reuse of a slot by itself (the host passes the downloads of group g before it issues the uploads of group
+        // g + 2) and costs nothing as long as the next group's kernels are enqueued first.
+        BatchGuard guard{e};
+        int cap = 1;
+        if ((rc = prepare_group(e, N, H, W, pl, &cap))) return rc;
+        if (cap >= 2) {
+            if (!e->chain_err.p) {
+                if ((rc = e->chain_err.ensure(16))) return rc;
+                HIP_TRY(hipMemsetAsync(e->chain_err.p, 0, 16, e->stream));
             }
-            for (int k = 0; k < n; k++) {
-                sgm_engine *q = k == 0 ? e : e->group[k - 1];
-                const size_t i = (size_t)(i0 + k);
-                if ((rc = q->in_left.ensure(npx)) || (rc = q->in_right.ensure(npx)) || (rc = q->disp_out.ensure(npx * 2))) return rc;
-                if (xyz_out && ((rc = q->f32.ensure(npx * 4)) || (rc = q->xyz.ensure(npx * 12)))) return rc;
-                HIP_TRY(hipMemcpyAsync(q->in_left.p, lefts + i * npx, npx, hipMemcpyHostToDevice, e->stream));
-                HIP_TRY(hipMemcpyAsync(q->in_right.p, rights + i * npx, npx, hipMemcpyHostToDevice, e->stream));
-                dl[k] = q->in_left.p;
-                dr[k] = q->in_right.p;
-                dd[k] = q->disp_out.p;
-                df[k] = xyz_out ? q->f32.p : nullptr;
-                dx[k] = xyz_out ? q->xyz.p : nullptr;
+            if (!e->copy_in) HIP_TRY(hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking));
+            if (!e->copy_out) HIP_TRY(hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking));
+            const int ngroups = (N + cap - 1) / cap, per = (N + ngroups - 1) / ngroups;
+            e->last_group = per - 1;
+            std::vector<sgm_engine *> eng(per);
+            for (int k = 0; k < per; k++) {
+                sgm_engine *q = eng[k] = k == 0 ? e : e->group[k - 1];
+                for (int sl = 0; sl < (ngroups > 1 ? 2 : 1); sl++) {
+                    if ((rc = q->io[sl][0].ensure(npx)) || (rc = q->io[sl][1].ensure(npx)) || (rc = q->io[sl][2].ensure(npx * 2))) return rc;
+                    if (xyz_out && ((rc = q->io[sl][3].ensure(npx * 4)) || (rc = q->io[sl][4].ensure(npx * 12)))) return rc;
+                    if (!q->ev_io_in[sl]) HIP_TRY(hipEventCreateWithFlags(&q->ev_io_in[sl], hipEventDisableTiming));
+                    if (!q->ev_io_out[sl]) HIP_TRY(hipEventCreateWithFlags(&q->ev_io_out[sl], hipEventDisableTiming));
+                }
             }
-            if ((rc = sgm_pipeline_batch_device(e, n, dl.data(), dr.data(), H, W, W, Q16, dd.data(), xyz_out ? df.data() : nullptr,
-                                                xyz_out ? dx.data() : nullptr))) {
-                (void)hipStreamSynchronize(e->stream);
-                return rc;
+            std::vector<const void *> dl(per), dr(per);
+            std::vector<void *> dd(per), df(per), dx(per);
+            std::vector<hipEvent_t> evi(per), evo(per);
+            auto upload = [&](int gi) -> int {     // images of group gi -> slot gi & 1, pair by pair
+                const int sl = gi & 1, i0 = gi * per, n = std::min(N - i0, per);
+                for (int k = 0; k < n; k++) {
+                    sgm_engine *q = eng[k];
+                    const size_t i = (size_t)(i0 + k);
+                    HIP_TRY(hipMemcpyAsync(q->io[sl][0].p, lefts + i * npx, npx, hipMemcpyHostToDevice, e->copy_in));
+                    HIP_TRY(hipMemcpyAsync(q->io[sl][1].p, rights + i * npx, npx, hipMemcpyHostToDevice, e->copy_in));
+                    HIP_TRY(hipEventRecord(q->ev_io_in[sl], e->copy_in));
+                }
+                return SGM_OK;
+            };
+            auto compute = [&](int gi) -> int {
+                const int sl = gi & 1, i0 = gi * per, n = std::min(N - i0, per);
+                for (int k = 0; k < n; k++) {
+                    sgm_engine *q = eng[k];
+                    q->hr_accumulate = gi > 0;
+                    dl[k] = q->io[sl][0].p;
+                    dr[k] = q->io[sl][1].p;
+                    dd[k] = q->io[sl][2].p;
+                    df[k] = xyz_out ? q->io[sl][3].p : nullptr;
+                    dx[k] = xyz_out ? q->io[sl][4].p : nullptr;
+                    evi[k] = q->ev_io_in[sl];
+                    evo[k] = q->ev_io_out[sl];
+                }
+                if (n == 1) {   // (a last group of one pair: the plain entry on e, behind its upload)
+                    HIP_TRY(hipStreamWaitEvent(e->stream, evi[0], 0));
+                    int r2 = sgm_pipeline_device(e, dl[0], dr[0], H, W, W, Q16, dd[0], df[0], dx[0]);
+                    if (r2) return r2;
+                    HIP_TRY(hipEventRecord(evo[0], e->stream));
+                    return SGM_OK;
+                }
+                return run_group(e, eng.data(), n, pl, dl.data(), dr.data(), H, W, W, Q16, dd.data(), xyz_out ? df.data() : nullptr,
+                                 xyz_out ? dx.data() : nullptr, evi.data(), evo.data());
+            };
+            auto download = [&](int gi) -> int {   // maps (and XYZ) of group gi, each as soon as its pair is done
+                const int sl = gi & 1, i0 = gi * per, n = std::min(N - i0, per);
+                for (int k = 0; k < n; k++) {
+                    sgm_engine *q = eng[k];
+                    const size_t i = (size_t)(i0 + k);
+                    HIP_TRY(hipStreamWaitEvent(e->copy_out, q->ev_io_out[sl], 0));
+                    HIP_TRY(hipMemcpyAsync(disps_out + i * npx, q->io[sl][2].p, npx * 2, hipMemcpyDeviceToHost, e->copy_out));
+                    if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out + i * npx * 3, q->io[sl][4].p, npx * 12, hipMemcpyDeviceToHost, e->copy_out));
+                }
+                return SGM_OK;
+            };
+            if ((rc = upload(0))) return rc;
+            for (int gi = 0; gi < ngroups; gi++) {
+                if ((rc = compute(gi))) return rc;
+                if (gi + 1 < ngroups && (rc = upload(gi + 1))) return rc;     // beside the kernels of group gi
+                if (gi > 0 && (rc = download(gi - 1))) return rc;              // (done since the kernels of gi were enqueued behind it)
             }
-            for (int k = 0; k < n; k++) {
-                const size_t i = (size_t)(i0 + k);
-                HIP_TRY(hipMemcpyAsync(disps_out + i * npx, dd[k], npx * 2, hipMemcpyDeviceToHost, e->stream));
-                if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out + i * npx * 3, dx[k], npx * 12, hipMemcpyDeviceToHost, e->stream));
-            }
+            if ((rc = download(ngroups - 1))) return rc;
+            HIP_TRY(hipStreamSynchronize(e->copy_out));
             HIP_TRY(hipStreamSynchronize(e->stream));
+            guard.ok = true;
+            return check_chain(e);
         }
-        return check_chain(e);
+        // (not even two pairs fit beside each other: pair after pair below)
     }
     const int neng = std::min(N, 3);
     if (neng > 1 && !e->peer && (rc = sgm_create(&e->params, e->device, nullptr, &e->peer))) return rc;
@@ -1755,10 +2093,11 @@ int sgm_valid_mask(sgm_engine *e, const float *xyz, const float *disp, int64_t n
     return SGM_OK;
 }
 
-int sgm_compact_points_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f32, const void *d_colors_rgb,
-                              int64_t n, void *d_out_points, void *d_out_colors, int64_t *n_valid)
+// the three launches of an ordered compaction on the engine's stream; the total stays in e->ccount[m]
+static int enqueue_compaction(sgm_engine *e, const void *d_xyz, const void *d_disp_f32, const void *d_colors_rgb, int64_t n,
+                              void *d_out_points, void *d_out_colors, int *m_out)
 {
-    if (!e || !d_xyz || !d_disp_f32 || !d_out_points || !n_valid || n <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    if (!e || !d_xyz || !d_disp_f32 || !d_out_points || n <= 0) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
     if (d_out_colors && !d_colors_rgb) return set_err(SGM_ERR_INVALID_ARG, "out_colors requested without colors");
     if (n >= (1ll << 32)) return set_err(SGM_ERR_UNSUPPORTED, "more than 2^32 points");
     HIP_TRY(hipSetDevice(e->device));
@@ -1773,10 +2112,34 @@ int sgm_compact_points_device(sgm_engine *e, const void *d_xyz, const void *d_di
                        (const uint8_t *)(d_out_colors ? d_colors_rgb : nullptr), n, (const uint32_t *)cnt,
                        (float *)d_out_points, (uint8_t *)d_out_colors);
     KCHECK();
+    *m_out = m;
+    return SGM_OK;
+}
+
+int sgm_compact_points_device(sgm_engine *e, const void *d_xyz, const void *d_disp_f32, const void *d_colors_rgb,
+                              int64_t n, void *d_out_points, void *d_out_colors, int64_t *n_valid)
+{
+    if (!n_valid) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    int m = 0;
+    int rc = enqueue_compaction(e, d_xyz, d_disp_f32, d_colors_rgb, n, d_out_points, d_out_colors, &m);
+    if (rc) return rc;
     uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, cnt + m, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(&total, (uint32_t *)e->ccount.p + m, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     *n_valid = (int64_t)total;
+    return SGM_OK;
+}
+
+// the same without a host round trip: the count goes to device memory (stream order), nothing is synchronised
+int sgm_compact_points_device_async(sgm_engine *e, const void *d_xyz, const void *d_disp_f32, const void *d_colors_rgb,
+                                    int64_t n, void *d_out_points, void *d_out_colors, void *d_n_valid_i64)
+{
+    if (!d_n_valid_i64) return set_err(SGM_ERR_INVALID_ARG, "bad argument");
+    int m = 0;
+    int rc = enqueue_compaction(e, d_xyz, d_disp_f32, d_colors_rgb, n, d_out_points, d_out_colors, &m);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compact_total, dim3(1), dim3(1), 0, e->stream, (const uint32_t *)e->ccount.p + m, (int64_t *)d_n_valid_i64);
+    KCHECK();
     return SGM_OK;
 }
 
@@ -1864,8 +2227,17 @@ int sgm_get_headroom(sgm_engine *e, int *max_cost_plus_p2, int *max_delta, int *
     if (e->H <= 0 || !e->headroom.p) return set_err(SGM_ERR_INVALID_ARG, "no compute has run yet");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    // the last call's record: after a batch call, the maximum over every pair of the batch (each pair of a chained group
+    // keeps its record on the internal engine that ran it; e's stream ends behind all of them)
     uint32_t h[2] = {0, 0};
     HIP_TRY(hipMemcpy(h, e->headroom.p, 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < e->last_group && k < (int)e->group.size(); k++) {
+        uint32_t q[2] = {0, 0};
+        if (!e->group[k]->headroom.p) continue;
+        HIP_TRY(hipMemcpy(q, e->group[k]->headroom.p, 8, hipMemcpyDeviceToHost));
+        h[0] = std::max(h[0], q[0]);
+        h[1] = std::max(h[1], q[1]);
+    }
     // an int16 lane upstream holds C_true + P2 and min_d L_r + P2: both must fit
     const int64_t a = e->g.W1 > 0 ? (int64_t)h[0] + e->g.P2 : 0, b = e->g.W1 > 0 ? (int64_t)h[1] + e->g.P2 : 0;
     if (max_cost_plus_p2) *max_cost_plus_p2 = (int)std::min<int64_t>(a, INT32_MAX);

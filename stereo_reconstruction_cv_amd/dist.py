@@ -204,6 +204,19 @@ class _Streams:
         ev.record(self.comm)
         return ev
 
+    def used_by_comm(self, *tensors):
+        """tensors allocated on another stream that the communication stream is about to read or write"""
+        if self.cuda:
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.comm)
+
+    def used_by_compute(self, *tensors):
+        if self.cuda and self.compute is not None:
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.compute)
+
     def compute_waits(self, ev):
         # an EVENT, not wait_stream(comm): the communication stream also carries the later gathers and scatters,
         # which the kernels of this batch must not wait for
@@ -214,7 +227,7 @@ class _Streams:
 class IngestPipeline:
     """Rank `src` owns the frames of every batch; results come back to it.  Two batches in flight:
 
-        step k:   post gather(k - 2)   |  post scatter(k)   |  compute(k - 1) enqueued behind scatter(k - 1)
+        step k:   finish gather(k - 3)  |  post gather(k - 2)  |  post scatter(k)  |  compute(k - 1) enqueued behind scatter(k - 1)
 
     so the transfers of batches k - 2 and k run beside the kernels of batch k - 1.  On the GPU box transfers are
     enqueued on a communication stream of their own and ordered against the compute stream with events only (the
@@ -222,26 +235,45 @@ class IngestPipeline:
     result tensors without synchronising.  Every rank must call `step` the same number of times with batches of
     the same frame count in the same order (`src` passes the tensors, the others None) and finish with `drain`.
 
+    Tensors cross streams here, and torch's caching allocator knows only the stream a tensor was allocated on: every
+    tensor that another stream reads or writes is announced with `record_stream` -- a result tensor (allocated on the
+    compute stream) before the communication stream sends or copies it, a scattered shard (allocated on the
+    communication stream) before the compute stream reads it -- so a block is never handed out again while a
+    transfer or a kernel of the other stream is still pending on it, whenever its last reference dies.
+
+    compact=True: `compute` returns (..., points [n, M, 3], counts [n] int64) -- the valid points of every frame packed
+    to the front of its row and their number (hip_batch_compute(compact=True); main.ipynb:726-737) -- and instead of
+    rows of M points only counts[i] points per frame travel.  A transfer needs its size on both sides when it is
+    posted, so the points follow the counts one step later:
+
+        step k:   finish points(k - 4)  |  finish gather(k - 3) [dense results + counts], post points(k - 3)  |  ... as above
+
+    Posting points(k - 3) reads counts on the host, i.e. waits until compute(k - 3) has finished -- while compute(k - 2),
+    enqueued a step earlier, keeps the GPU busy: one host wait per step, none per frame.  `src` gets, per batch,
+    (dense results ..., [points of frame i: (counts[i], 3)], counts [N]).
+
     Frame shape and dtype are announced once (`first batch`); later batches must keep the shape.
     """
 
     def __init__(self, compute: Callable, src: int = 0, device: Optional[torch.device] = None, group=None,
-                 compute_stream=None):
+                 compute_stream=None, compact: bool = False):
         self.compute, self.src, self.group = compute, src, group
         self.rank, self.world = _world(group)
         self.device = device if device is not None else torch.device("cpu")
         self.s = _Streams(self.device, compute_stream)
+        self.compact = compact
         self.shape = self.dtype = None
         self.k = 0
-        self.scattered = {}    # k -> (l, r, batch_l, batch_r)
-        self.computed = {}     # k -> (results tuple, many?, event)
-        self.gathering = {}    # k -> (outs, batches)
+        self.scattered = {}    # k -> (l, r, event behind the scatter)
+        self.computed = {}     # k -> (results tuple, many?, event behind the kernels)
+        self.gathering = {}    # k -> (posted, many?, ragged)
+        self.gathering2 = {}   # k -> (dense outs, point tensors, counts, batch)       (compact only)
         self.done: List = []   # on src: results in batch order
         self.in_bufs = [[None, None], [None, None], [None, None]]   # receive buffers, 3 deep (scatter k + 2 beside compute k + 1 beside gather k)
 
     def _post_scatter(self, k, lefts, rights):
         if self.world == 1:
-            self.scattered[k] = (lefts.to(self.device), rights.to(self.device), None, None)
+            self.scattered[k] = (lefts.to(self.device), rights.to(self.device), None)
             return
         if self.shape is None:
             self.shape, self.dtype = _announce(lefts, self.src, self.group)
@@ -254,69 +286,119 @@ class IngestPipeline:
             bl.wait()     # (NCCL: the communication stream waits, not the host)
             br.wait()
             landed = self.s.event_on_comm()
-        self.scattered[k] = (l, r, landed, None)
+        self.scattered[k] = (l, r, landed)
 
     def _compute(self, k):
-        l, r, landed, _ = self.scattered.pop(k)
+        l, r, landed = self.scattered.pop(k)
         self.s.compute_waits(landed)
+        self.s.used_by_compute(l, r)
         res = self.compute(l, r)
         many = isinstance(res, (tuple, list))
         self.computed[k] = (tuple(res) if many else (res,), many, self.s.event_after_compute())
 
     def _post_gather(self, k):
         res, many, ev = self.computed.pop(k)
+        ragged = None
+        if self.compact:
+            if len(res) < 2:
+                raise ValueError("IngestPipeline(compact=True): compute must return (..., points, counts)")
+            ragged = (res[-2], res[-1], ev)
+            res = res[:-2] + (res[-1],)          # the counts travel with the dense results
         if self.world == 1:
-            self.done.append(res if many else res[0])
+            if self.compact:
+                self.gathering[k] = ([(t, None) for t in res], many, ragged)
+            else:
+                self.done.append(res if many else res[0])
             return
         n = self.shape[0]
         with self.s.on_comm():
             self.s.comm_waits(ev)
+            self.s.used_by_comm(*res)
             posted = [post_gather(t, n, self.src, self.group) for t in res]
-        self.gathering[k] = (posted, many)
+        self.gathering[k] = (posted, many, ragged)
 
     def _finish_gather(self, k):
         if k not in self.gathering:    # (a single process gathers nothing)
             return
-        posted, many = self.gathering.pop(k)
+        posted, many, ragged = self.gathering.pop(k)
         with self.s.on_comm():
             for _, b in posted:
-                b.wait()
-        if self.rank == self.src:
-            outs = tuple(o for o, _ in posted)
-            self.done.append(outs if many else outs[0])
+                if b is not None:
+                    b.wait()
+        outs = tuple(o for o, _ in posted)
+        if ragged is None:
+            if self.rank == self.src:
+                self.done.append(outs if many else outs[0])
+            return
+        # ---- compact: the counts are here (on src: everybody's); now the points, exactly counts[i] per frame
+        points, counts, ev = ragged
+        if self.s.cuda and ev is not None:
+            ev.synchronize()                 # (compute(k) is done; compute(k + 1) was enqueued a step ago)
+        mine = [int(c) for c in counts.cpu().tolist()]
+        b = _Batch(self.group)
+        if self.world == 1:
+            self.gathering2[k] = (outs[:-1], [points[i, :c] for i, c in enumerate(mine)], counts, b)
+            return
+        n = self.shape[0]
+        with self.s.on_comm():
+            self.s.used_by_comm(points)
+            if self.rank != self.src:
+                for i, c in enumerate(mine):
+                    b.send(points[i, :c].contiguous(), self.src)
+                self.gathering2[k] = (None, None, None, b.post())
+                return
+            if self.s.cuda:
+                self.s.comm.synchronize()    # the gathered counts have landed (posted a step ago)
+            allc = outs[-1]
+            every = [int(c) for c in allc.cpu().tolist()]
+            pts: List[Optional[torch.Tensor]] = [None] * n
+            for r in range(self.world):
+                a, e = shard_range(n, r, self.world)
+                for i in range(a, e):
+                    if r == self.src:
+                        pts[i] = points[i - a, :every[i]]
+                    else:
+                        pts[i] = torch.empty((every[i], 3), dtype=points.dtype, device=points.device)
+                        b.recv(pts[i], r)
+            self.gathering2[k] = (outs[:-1], pts, allc, b.post())
 
-    def step(self, lefts: Optional[torch.Tensor], rights: Optional[torch.Tensor]):
-        """Feed batch k.  Order inside a step (the same on every rank, so that transfers pair up): finish gather(k - 3),
-        post gather(k - 2), post scatter(k), enqueue compute(k - 1)."""
-        k = self.k
+    def _finish_points(self, k):
+        dense, pts, counts, b = self.gathering2.pop(k)
+        with self.s.on_comm():
+            b.wait()
+        if self.rank == self.src:
+            self.done.append(tuple(dense) + (pts, counts))
+
+    def _tick(self, k, lefts, rights, feed: bool):
+        """One step of the schedule (the same order on every rank, so that transfers pair up)."""
+        if k - 4 in self.gathering2:
+            self._finish_points(k - 4)
         if k - 3 in self.gathering:
             self._finish_gather(k - 3)
         if k - 2 in self.computed:
             self._post_gather(k - 2)
-        self._post_scatter(k, lefts, rights)
+        if feed:
+            self._post_scatter(k, lefts, rights)
         if k - 1 in self.scattered:
             self._compute(k - 1)
+
+    def step(self, lefts: Optional[torch.Tensor], rights: Optional[torch.Tensor]):
+        """Feed batch k: finish gather(k - 3), post gather(k - 2), post scatter(k), enqueue compute(k - 1)."""
+        self._tick(self.k, lefts, rights, True)
         self.k += 1
 
     def drain(self):
-        """Finish everything in flight; returns (on `src`) the list of per-batch results, else an empty list."""
-        k = self.k
-        for j in (k - 3, k - 2, k - 1):
-            if j in self.gathering:
-                self._finish_gather(j)
-        if k - 2 in self.computed:
-            self._post_gather(k - 2)
-        if k - 1 in self.scattered:
-            self._compute(k - 1)
-        if k - 2 in self.gathering:
-            self._finish_gather(k - 2)
-        if k - 1 in self.computed:
-            self._post_gather(k - 1)
-            self._finish_gather(k - 1)
+        """Finish everything in flight; returns (on `src`) the list of per-batch results, else an empty list.  Raises if
+        the engine behind `compute` reports an error for the work it was handed without synchronising (compute.check)."""
+        for j in range(5):
+            self._tick(self.k + j, None, None, False)
         if self.s.cuda:
             self.s.comm.synchronize()
             if self.s.compute is not None:
                 self.s.compute.synchronize()
+        check = getattr(self.compute, "check", None)
+        if check is not None:
+            check()
         out, self.done = self.done, []
         self.k = 0
         return out
@@ -334,10 +416,13 @@ def hip_batch_compute(params: dict, Q=None, want_float: bool = False, schedule: 
     launch per pass, sgm_pipeline_batch_device).  stream: a torch.cuda.Stream the engine works on (default: a
     stream of its own); synchronize=False returns as soon as the work is enqueued (IngestPipeline orders it with
     events).  compact=True (needs Q): instead of the dense XYZ image -- 12 bytes per pixel, 99.5 MB per 4K pair --
-    the call returns (disparity, points [n, H*W, 3] float32, counts [n] int64): the valid points of every frame
-    (main.ipynb:726-737: finite X and disparity > 0) packed to the front of its row, the rest of the row zero;
-    a consumer that only wants the cloud gathers counts first and then counts[i] points per frame
-    (gather_compacted)."""
+    the call returns (disparity, points [n, H*W, 3] float32, counts [n] int64 on the device): the valid points of every
+    frame (main.ipynb:726-737: finite X and disparity > 0) packed to the front of its row (the rest of the row is
+    unspecified), computed in stream order without a host round trip; a consumer that only wants the cloud gathers
+    counts first and then counts[i] points per frame (gather_compacted, IngestPipeline(compact=True)).
+
+    The returned callable has a `check()` attribute (Engine.check of the engines it used): IngestPipeline.drain calls
+    it, so a chained sweep that gave up inside stream-ordered work is reported instead of handing wrong maps on."""
     import numpy as np
 
     from . import _lib as _l
@@ -385,17 +470,33 @@ def hip_batch_compute(params: dict, Q=None, want_float: bool = False, schedule: 
             eng.pipeline_batch_device(ptrs(lefts), ptrs(rights), H, W, W, Qm, ptrs(disp),
                                       ptrs(dispf) if Qm is not None else None, ptrs(xyz) if Qm is not None else None)
         if compact:
-            pts = torch.zeros((n, H * W, 3), dtype=torch.float32, device=dev)
-            counts = torch.zeros((n,), dtype=torch.int64)
-            for i in range(n):     # (synchronises per frame: the count comes back to the host)
-                counts[i] = eng.compact_points_device(xyz[i].data_ptr(), dispf[i].data_ptr(), None, H * W, pts[i].data_ptr(), None)
-            return disp, pts, counts.to(dev)
+            # valid points of every frame packed to the front of its row, counts in device memory: three launches and a
+            # one-thread kernel per frame on the engine's stream, no host round trip (sgm_compact_points_device_async)
+            # (torch.empty: nothing is enqueued on torch's stream that the engine's stream could race with -- round 3 zero-filled
+            #  the rows there; every count is written by the engine, rows past the count are unspecified)
+            pts = torch.empty((n, H * W, 3), dtype=torch.float32, device=dev)
+            counts = torch.empty((n,), dtype=torch.int64, device=dev)
+            if stream is not None:
+                pts.record_stream(stream)
+                counts.record_stream(stream)
+            for i in range(n):
+                eng.compact_points_device_async(xyz[i].data_ptr(), dispf[i].data_ptr(), None, H * W, pts[i].data_ptr(), None,
+                                                counts[i:].data_ptr())
+            if synchronize:
+                eng.synchronize()
+            return disp, pts, counts
         if synchronize:
             eng.synchronize()
         if Qm is None:
             return disp
         return (disp, dispf, xyz) if want_float else (disp, xyz)
 
+    def check():
+        """status of the engines this callable has used, without waiting for them (Engine.check)"""
+        for e in own.values():
+            e.check()
+
+    compute.check = check
     return compute
 
 

@@ -90,6 +90,15 @@ class Engine:
     def synchronize(self) -> None:
         _check(self._L.sgm_synchronize(self._h))
 
+    def check(self) -> None:
+        """Status WITHOUT waiting for the engine's stream (sgm_check): raises if a chained sweep gave up since the last
+        check -- for callers that order the engine's stream with events of their own."""
+        _check(self._L.sgm_check(self._h))
+
+    def trim(self) -> None:
+        """Give back the internal engines (and their device memory) the batch entries created (sgm_trim)."""
+        _check(self._L.sgm_trim(self._h))
+
     def stage_times(self):
         st = _lib.SgmStageTimes()
         _check(self._L.sgm_get_stage_times(self._h, C.byref(st)))
@@ -174,6 +183,12 @@ class Engine:
         nv = C.c_int64(0)
         _check(self._L.sgm_compact_points_device(self._h, d_xyz, d_dispf, d_colors, n, d_points, d_out_colors, C.byref(nv)))
         return int(nv.value)
+
+    def compact_points_device_async(self, d_xyz: int, d_dispf: int, d_colors: int | None, n: int, d_points: int,
+                                    d_out_colors: int | None, d_count_i64: int) -> None:
+        """The same in stream order (sgm_compact_points_device_async): the count goes to an int64 in DEVICE memory,
+        nothing is synchronised."""
+        _check(self._L.sgm_compact_points_device_async(self._h, d_xyz, d_dispf, d_colors, n, d_points, d_out_colors, d_count_i64))
 
     def median3x3_host(self, img: np.ndarray) -> np.ndarray:
         img = np.ascontiguousarray(img, np.int16)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     for name in _declared_symbols():
         assert hasattr(L, name), name
-    assert L.sgm_abi_version() == _lib.ABI_VERSION == 3
+    assert L.sgm_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_parameter_validation_and_geometry_need_no_gpu():

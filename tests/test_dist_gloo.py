@@ -177,6 +177,84 @@ def test_gather_of_compacted_point_lists(world, n):
     assert len(msgs) == world
 
 
+def _fake_compute_compact(l, r):
+    """(maps, points, counts)-shaped result: frame i of a shard has `sum of its left image mod M` valid points at the front of
+    its row of M (what hip_batch_compute(compact=True) returns; rows past the count hold junk that must not travel)"""
+    d = _fake_compute(l, r)
+    n, M = l.shape[0], 37
+    counts = (l.reshape(n, -1).to(torch.int64).sum(dim=1) % (M + 1)) if n else torch.zeros((0,), dtype=torch.int64)
+    pts = torch.full((n, M, 3), -1.0)
+    for i in range(n):
+        c = int(counts[i])
+        pts[i, :c] = torch.arange(c * 3, dtype=torch.float32).reshape(c, 3) + float(d[i].sum())
+    return d, pts, counts
+
+
+def _compact_pipeline_worker(rank, world, port, n, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batches = _batches(n, steps)
+        pipe = D.IngestPipeline(_fake_compute_compact, src=0, compact=True)
+        for rep in range(2):        # twice: reuse of the pipeline object
+            for l, r in batches:
+                pipe.step(l if rank == 0 else None, r if rank == 0 else None)
+                assert len(pipe.gathering) <= 2 and len(pipe.gathering2) <= 2
+            res = pipe.drain()
+            if rank == 0:
+                assert len(res) == steps
+                for (l, r), (d, pts, counts) in zip(batches, res):
+                    wd, wp, wc = _fake_compute_compact(l, r)
+                    assert torch.equal(d, wd) and torch.equal(counts, wc)
+                    assert len(pts) == n
+                    for i in range(n):          # exactly counts[i] points per frame, the frame's own, in order
+                        assert pts[i].shape == (int(wc[i]), 3) and torch.equal(pts[i], wp[i, :int(wc[i])])
+            else:
+                assert res == []
+        q.put(("ok", rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,steps", [(2, 5, 4), (3, 4, 6), (2, 1, 2), (3, 7, 1), (2, 4, 3)])
+def test_compact_ingest_pipeline_sends_counts_ahead_of_exactly_that_many_points(world, n, steps):
+    """IngestPipeline(compact=True): dense maps and counts are gathered as before, the points one step later and exactly
+    counts[i] of them per frame (ragged and empty shards, zero-point frames, fewer steps than the pipeline is deep, reuse)."""
+    procs, q = _spawn(_compact_pipeline_worker, world, n, steps)
+    msgs = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(m[1] for m in msgs) == list(range(world))
+
+
+def test_compact_pipeline_single_process():
+    batches = _batches(3, 4)
+    pipe = D.IngestPipeline(_fake_compute_compact, compact=True)
+    for l, r in batches:
+        pipe.step(l, r)
+    res = pipe.drain()
+    assert len(res) == 4
+    for (l, r), (d, pts, counts) in zip(batches, res):
+        wd, wp, wc = _fake_compute_compact(l, r)
+        assert torch.equal(d, wd) and torch.equal(counts, wc)
+        assert all(torch.equal(pts[i], wp[i, :int(wc[i])]) for i in range(3))
+
+
+def test_drain_reports_what_the_engine_behind_compute_says():
+    """compute.check (hip_batch_compute: Engine.check of the engines it used) is called by drain: an engine error inside
+    stream-ordered work surfaces there instead of wrong maps being handed on"""
+    def compute(l, r):
+        return _fake_compute(l, r)
+    compute.check = lambda: (_ for _ in ()).throw(RuntimeError("chained sweep gave up"))
+    pipe = D.IngestPipeline(compute)
+    pipe.step(*_batches(2, 1)[0])
+    with pytest.raises(RuntimeError, match="gave up"):
+        pipe.drain()
+
+
 def test_pipeline_single_process():
     batches = _batches(3, 3)
     pipe = D.IngestPipeline(_fake_compute)

@@ -123,15 +123,19 @@ def test_c3_c5_4k_d256_hh_pipeline_device_with_xyz():
     assert {"sweep_dn", "sweep_up", "wta", "float_xyz"} <= set(names)
 
 
-def run_batch_device(frames, p, Q, schedule=2):
-    """sgm_pipeline_batch_device on resident pairs, as `bench.py --batch` calls it (profiling on, two rounds)"""
+def run_batch_device(frames, p, Q, schedule=2, repeat_to=0):
+    """sgm_pipeline_batch_device on resident pairs, as `bench.py --batch` calls it (profiling on, two rounds).
+    repeat_to = N > len(frames): the batch holds N pairs, pair i a copy of frames[i % len(frames)] in buffers of its own (the
+    bench does the same: a handful of different images, every pair computed); returned are the results of the first
+    len(frames) pairs and, for the others, whether their three outputs equal their source pair's bit for bit."""
     import torch
     import stereo_reconstruction_cv_amd as cv
     H, W = frames[0][0].shape
-    n = len(frames)
+    nu = len(frames)
+    n = max(repeat_to, nu)
     dev = torch.device("cuda", 0)
-    dl = [torch.from_numpy(a).to(dev) for a, _ in frames]
-    dr = [torch.from_numpy(b).to(dev) for _, b in frames]
+    dl = [torch.from_numpy(frames[i % nu][0]).to(dev) for i in range(n)]
+    dr = [torch.from_numpy(frames[i % nu][1]).to(dev) for i in range(n)]
     dd = [torch.empty((H, W), dtype=torch.int16, device=dev) for _ in range(n)]
     df = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(n)] if Q is not None else None
     dx = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(n)] if Q is not None else None
@@ -141,25 +145,44 @@ def run_batch_device(frames, p, Q, schedule=2):
     eng.set_option(_lib.SGM_OPT_SCHEDULE, schedule)
     ptr = lambda ts: [t.data_ptr() for t in ts] if ts is not None else None
     for _ in range(2):
+        for t in dd:
+            t.fill_(-7)
+        torch.cuda.synchronize(dev)
         eng.pipeline_batch_device(ptr(dl), ptr(dr), H, W, W, Q, ptr(dd), ptr(df), ptr(dx))
         eng.synchronize()
     names = [nm for nm, _, _ in eng.stage_times()]
+    assert eng.headroom()["ok"]          # (the record of a batch call covers every pair of it)
     out = [(dd[i].cpu().numpy(), df[i].cpu().numpy() if Q is not None else None, dx[i].cpu().numpy() if Q is not None else None)
-           for i in range(n)]
+           for i in range(nu)]
+    # bitwise comparison of the repeats (int32 views: NaN payloads and the sign of zero count)
+    same = [bool(torch.equal(dd[i], dd[i % nu]) and (Q is None or (torch.equal(df[i].view(torch.int32), df[i % nu].view(torch.int32)) and
+                                                                  torch.equal(dx[i].view(torch.int32), dx[i % nu].view(torch.int32)))))
+            for i in range(nu, n)]
     del eng
-    return out, names
+    return out, names, same
+
+
+def bench_workload(name):
+    """(H, W, D, blockSize, mode, pairs per step, reproject) of a bench.py workload: the tests below run the bench's own batch"""
+    import bench
+    H, W, D, bs, mode, ppg, with_xyz, schedule, batch, _ = bench.WORKLOADS[name]
+    assert schedule == 2 and batch
+    return H, W, D, bs, mode, ppg, with_xyz
 
 
 def test_c3_c5_4k_d256_hh_throughput_mode_batch():
-    """bench.py's default workload in throughput mode: 3840x2160, D=256, MODE_HH + reprojection, several pairs through
-    sgm_pipeline_batch_device with chained sweeps (SGM_OPT_SCHEDULE 2: no pre-pass, ONE sweep launch per pass for the
-    whole group).  Three pairs of a group, two different images (the third pair repeats the first in another slot of the
-    group): every map, float map and XYZ image equals the oracle's for its own pair."""
-    H, W, D, bs = 2160, 3840, 256, 7
+    """bench.py's DEFAULT workload, as the bench runs it: 3840x2160, D=256, MODE_HH + reprojection, the default's own
+    number of pairs per step (17) through ONE call of sgm_pipeline_batch_device with chained sweeps (SGM_OPT_SCHEDULE 2:
+    no pre-pass, one sweep launch per pass for the whole group).  Two different images fill the batch alternately: the
+    first two pairs' maps, float maps and XYZ images equal the oracle's, every other pair equals its source pair bit for
+    bit -- computed in a slot of its own, on an engine of its own."""
+    import bench
+    H, W, D, bs, mode, ppg, with_xyz = bench_workload(bench.DEFAULT_WORKLOAD)
+    assert (H, W, D, bs, mode, with_xyz) == (2160, 3840, 256, 7, 1, True) and ppg >= 12
     Q = synth.default_Q(W)
-    seeds = (1234, 1235, 1234)
+    seeds = (1234, 1235)
     frames = [synth.make_pair(H, W, D, s)[:2] for s in seeds]
-    outs, names = run_batch_device(frames, nb_params(D, bs, 1), Q)
+    outs, names, same = run_batch_device(frames, nb_params(D, bs, mode), Q, repeat_to=ppg)
     assert {"chain_dn", "chain_up", "wta", "float_xyz"} <= set(names) and "prepass_dn" not in names
     for i, s in enumerate(seeds):
         want, wf, wxyz = oracle_4k(D, bs, 1, s, True)
@@ -167,6 +190,23 @@ def test_c3_c5_4k_d256_hh_throughput_mode_batch():
         assert int((got != want).sum()) == 0, f"pair {i}: {int((got != want).sum())} of {got.size} differ"
         assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32))
         check_xyz(gxyz, wxyz)
+    assert len(same) == ppg - 2 and all(same), [i + 2 for i, ok in enumerate(same) if not ok]
+
+
+@pytest.mark.parametrize("workload", ["c4t", "c1t"])
+def test_bench_batches_of_smaller_frames_at_their_own_size(workload):
+    """The other throughput-mode workloads of bench.py with their own pair counts: c4t = 32 pairs 1920x1080 D=128 (half of
+    BASELINE configs[3] on one GPU; the fifth path beside the chained sweep into a volume of its own), c1t = 64 pairs
+    1280x720 D=64 (k_sweep_chain<1, partial>: half the lanes idle).  Two different images alternate."""
+    H, W, D, bs, mode, ppg, with_xyz = bench_workload(workload)
+    p = nb_params(D, bs, mode)
+    frames = [synth.make_pair(H, W, D, s)[:2] for s in (1234, 1235)]
+    outs, names, same = run_batch_device(frames, p, None, repeat_to=ppg)
+    assert "chain_dn" in names
+    for i, (a, b) in enumerate(frames):
+        want, _, _ = oracle_frame(a, b, p)
+        assert int((outs[i][0] != want).sum()) == 0, f"pair {i}: {int((outs[i][0] != want).sum())} differ"
+    assert len(same) == ppg - 2 and all(same), [i + 2 for i, ok in enumerate(same) if not ok]
 
 
 @pytest.mark.parametrize("D,mode", [(256, 0), (128, 0)])
@@ -193,7 +233,7 @@ def test_4k_5path_chained_single_pair_and_batch(D, mode):
         got = dd.cpu().numpy()
         assert int((got != want).sum()) == 0
     else:
-        outs, names = run_batch_device([(l, r), (l, r)], p, None)
+        outs, names, _ = run_batch_device([(l, r), (l, r)], p, None)
         assert "chain_dn" in names and "path_W" in names
         for got, _, _ in outs:
             assert int((got != want).sum()) == 0

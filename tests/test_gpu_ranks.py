@@ -28,5 +28,8 @@ def test_two_ranks_share_the_gpu_and_the_ingest_pipeline_reproduces_the_resident
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "BENCH_REHEARSE" in d["data"]
     assert d["ingest_rank0"]["ok"] is True, d["ingest_rank0"]
+    # both forms of the gather: dense XYZ images, and the compacted point lists (counts one step ahead of the points)
+    assert d["ingest_rank0"]["dense"]["ok"] is True and d["ingest_rank0"]["compact"]["ok"] is True, d["ingest_rank0"]
+    assert d["ingest_rank0"]["pairs_per_rank"] == d["config"]["pairs_per_gpu_per_step"]
     assert d["ingest_rank0"]["backend"] == "gloo" and d["ingest_rank0"]["frames_per_step"] == 2 * d["config"]["pairs_per_gpu_per_step"]
     assert d["config"]["batch_entry"] is (workload == "tinyt")
