@@ -76,6 +76,8 @@ WORKLOADS = {
                 "batch of seventeen 3840x2160 D=256 bs=7 MODE_HH 8-path pairs per step (+ LR + subpixel + median + speckle + "
                 "reprojectImageTo3D), throughput mode: chained sweeps, one sweep launch per pass for the batch (17 engines = 221 GB; "
                 "17 x 180 bands = 11.95 tickets per persistent workgroup: no idle tail)"),
+    "c3c5x24": (2160, 3840, 256, 7, 1, 24, True, 2, True, "batch of twenty-four 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject): 24 engines = 223 GB"),
+    "c3c5x8": (2160, 3840, 256, 7, 1, 8, True, 2, True, "batch of eight 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject)"),
     "c3c5x18": (2160, 3840, 256, 7, 1, 18, True, 2, True, "batch of eighteen 4K D=256 MODE_HH pairs per step, throughput mode (+ reproject): 18 engines = 234 GB"),
     "c5x12": (2160, 3840, 256, 7, 0, 12, True, 2, True, "batch of twelve 4K D=256 5-path pairs per step + reproject, throughput mode"),
     "c5x17": (2160, 3840, 256, 7, 0, 17, True, 2, True, "batch of seventeen 4K D=256 5-path pairs per step + reproject, throughput mode (11.95 band tickets per workgroup)"),

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels_cost.h"
@@ -211,7 +212,10 @@ struct sgm_engine {
     // float map, XYZ -- with an event behind the upload and one behind the pair's last kernel; the engine the caller
     // holds owns the two copy streams.
     DevBuf io[2][5];
-    hipEvent_t ev_io_in[2] = {nullptr, nullptr}, ev_io_out[2] = {nullptr, nullptr};
+    HostBuf pin_io[2][3];                 // page-locked staging of the slot's images (left, right) and of its int16 map
+    // events of a slot: images uploaded / images consumed by the cost stage / last kernel of the pair done / map downloaded
+    hipEvent_t ev_io_in[2] = {nullptr, nullptr}, ev_io_used[2] = {nullptr, nullptr}, ev_io_out[2] = {nullptr, nullptr},
+               ev_io_dl[2] = {nullptr, nullptr};
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     hipEvent_t ev_group = nullptr;
     HostBuf pin_left, pin_right, pin_disp;
@@ -1376,8 +1380,11 @@ void sgm_destroy(sgm_engine *e)
     }
     release_buffers(e);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : e->ev_io_in) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : e->ev_io_out) if (ev) (void)hipEventDestroy(ev);
+    for (auto *evs : {e->ev_io_in, e->ev_io_used, e->ev_io_out, e->ev_io_dl})
+        for (int k = 0; k < 2; k++)
+            if (evs[k]) (void)hipEventDestroy(evs[k]);
+    for (auto &slot : e->pin_io)
+        for (HostBuf &b : slot) b.release();
     if (e->aux2) {
         (void)hipStreamSynchronize(e->aux2);
         (void)hipEventDestroy(e->ev_join2);
@@ -1469,6 +1476,8 @@ int sgm_trim(sgm_engine *e)
     e->pin_left.release();
     e->pin_right.release();
     e->pin_disp.release();
+    for (auto &slot : e->pin_io)
+        for (HostBuf &b : slot) b.release();
     return check_chain(e);
 }
 
@@ -1661,9 +1670,9 @@ static int prepare_pair_buffers(sgm_engine *q, int H, int W, const Plan &pl)
 }
 
 // The engines of a chained group for up to `want` pairs: e itself + internal engines, created, configured like e and
-// sized for the shape.  Fewer than `want` when device memory runs out (or would drop below a reserve of 1 GiB / 2 %:
+// sized for the shape.  Fewer than `want` when device memory runs out (or would drop below a reserve of 4 GiB / 5 %:
 // the caller and the runtime need room too) -- a batch then simply takes more groups.  *n_out >= 1.
-static int prepare_group(sgm_engine *e, int want, int H, int W, const Plan &pl, int *n_out)
+static int prepare_group(sgm_engine *e, int want, int H, int W, const Plan &pl, int *n_out, size_t extra_per_pair = 0)
 {
     int rc;
     *n_out = 0;
@@ -1690,7 +1699,11 @@ static int prepare_group(sgm_engine *e, int want, int H, int W, const Plan &pl, 
         const bool sized = q->H == H && q->W == W && q->cost.p;     // (ran this shape before: nothing to allocate)
         rc = prepare_pair_buffers(q, H, W, pl);
         size_t fr = 0, tot = 0;
-        if (!rc && !sized && hipMemGetInfo(&fr, &tot) == hipSuccess && fr < std::max<size_t>((size_t)1 << 30, tot / 50))
+        // (the reserve: 4 GiB or 5 % -- every stream, event pool and first launch of a kernel costs the runtime device memory
+        //  too, and "out of memory" from a kernel launch cannot be recovered from -- plus what the caller of this function
+        //  is about to allocate per pair: the host entry's transfer slots)
+        if (!rc && !sized && hipMemGetInfo(&fr, &tot) == hipSuccess &&
+            fr < std::max<size_t>((size_t)4 << 30, tot / 20) + extra_per_pair * (size_t)(k + 1))
             rc = SGM_ERR_NOMEM;
         if (rc == SGM_ERR_NOMEM) {
             release_buffers(q);   // (a half-sized engine would only hold memory the smaller group could use)
@@ -1720,12 +1733,13 @@ struct BatchGuard {
     }
 };
 
-// One group (n >= 2 pairs on eng[0 .. n-1], eng[0] = e) through cost stages, joint sweeps, epilogues.  in_ready[k] (may be
-// null): an event pair k's cost stage waits for (its images have arrived); out_done[k] (may be null): recorded behind
-// pair k's last kernel.
+// One group (n >= 2 pairs on eng[0 .. n-1], eng[0] = e) through cost stages, joint sweeps, epilogues.  The host entry
+// passes three event arrays (all null for resident pairs): in_ready[k] -- pair k's cost stage waits for it (its images have
+// arrived); in_used[k] -- recorded when pair k's images have been read for the last time (k_features); out_done[k] -- recorded
+// behind pair k's last kernel.
 static int run_group(sgm_engine *e, sgm_engine *const *eng, int n, const Plan &pl, const void *const *d_left, const void *const *d_right,
                      int H, int W, int64_t stride_bytes, const double Q[16], void *const *d_disp_i16, void *const *d_disp_f32,
-                     void *const *d_xyz_f32, const hipEvent_t *in_ready, const hipEvent_t *out_done)
+                     void *const *d_xyz_f32, const hipEvent_t *in_ready, const hipEvent_t *in_used, const hipEvent_t *out_done)
 {
     int rc;
     // cost stage of every pair on the stream of its own engine, from where `e`'s stream stands now (the caller's
@@ -1740,6 +1754,7 @@ static int run_group(sgm_engine *e, sgm_engine *const *eng, int n, const Plan &p
                               (int16_t *)d_disp_i16[k], PH_PRE)))
             return rc;
         if (!eng[k]->plan_chain) return set_err(SGM_ERR_HIP, "internal: a pair of a chained group did not plan a chained sweep");
+        if (in_used && in_used[k]) HIP_TRY(hipEventRecord(in_used[k], eng[k]->stream));   // (behind the whole cost stage: the images are read by its first kernel only)
     }
     // ---- the sweeps of all n pairs: one launch per pass on e's stream, behind every pair's cost stage
     const Geom &g = e->g;
@@ -1775,6 +1790,10 @@ static int run_group(sgm_engine *e, sgm_engine *const *eng, int n, const Plan &p
     // ---- the rest of every pair on its own stream (memory-bound kernels of different pairs side by side)
     for (int k = 0; k < n; k++) {
         if (k > 0) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, e->ev_group, 0));
+        // Host entry: the epilogues three at a time, not all at once -- they are bound by HBM either way, and pair k's map
+        // can travel to the host while the epilogues of the pairs behind it still run (all n at once end together: the
+        // whole group's download would follow the last kernel).
+        if (out_done && k >= 3 && out_done[k - 3]) HIP_TRY(hipStreamWaitEvent(eng[k]->stream, out_done[k - 3], 0));
         if ((rc = run_compute(eng[k], (const uint8_t *)d_left[k], (const uint8_t *)d_right[k], H, W, stride_bytes,
                               (int16_t *)d_disp_i16[k], PH_POST)))
             return rc;
@@ -1858,7 +1877,7 @@ int sgm_pipeline_batch_device(sgm_engine *e, int N, const void *const *d_left, c
             continue;
         }
         if ((rc = run_group(e, eng.data(), n, pl, d_left + i0, d_right + i0, H, W, stride_bytes, Q, d_disp_i16 + i0,
-                            d_disp_f32 ? d_disp_f32 + i0 : nullptr, d_xyz_f32 ? d_xyz_f32 + i0 : nullptr, nullptr, nullptr)))
+                            d_disp_f32 ? d_disp_f32 + i0 : nullptr, d_xyz_f32 ? d_xyz_f32 + i0 : nullptr, nullptr, nullptr, nullptr)))
             return rc;
     }
     guard.ok = true;
@@ -1880,6 +1899,25 @@ int sgm_compute(sgm_engine *e, const uint8_t *left, const uint8_t *right, int H,
     HIP_TRY(hipMemcpyAsync(disp_out, e->disp_out.p, npx * 2, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return check_chain(e);
+}
+
+// memcpy between pageable and page-locked host memory with a few threads (large blocks only: one thread moves about
+// 10 GB/s, a 4K frame is 8 - 17 MB)
+static void host_copy(void *dst, const void *src, size_t bytes)
+{
+    const int nt = bytes >= ((size_t)4 << 20) ? 4 : 1;
+    if (nt == 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
+    std::thread th[3];
+    for (int t = 1; t < nt; t++) {
+        const size_t o = std::min(bytes, part * t), n = std::min(bytes - o, part);
+        th[t - 1] = std::thread([=] { std::memcpy((char *)dst + o, (const char *)src + o, n); });
+    }
+    std::memcpy(dst, src, std::min(bytes, part));
+    for (int t = 1; t < nt; t++) th[t - 1].join();
 }
 
 // N independent pairs from / to host memory.  Up to three pairs are in flight: pair i runs on engine
@@ -1905,15 +1943,21 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
     if (joint) {
         // Throughput mode: chained groups as large as device memory holds, TWO groups in flight -- while the kernels of
         // group g run, the images of group g + 1 are uploaded and the maps of group g - 1 downloaded on two copy streams
-        // of their own.  Every pair has its device images twice (slot g & 1) on the engine that runs it, an event behind
-        // its upload (its cost stage waits for that one only: the first kernels start when the first pair has arrived,
-        // not the whole group) and one behind its last kernel (its download waits for that one only).  The caller's
-        // memory is pageable: hipMemcpyAsync from / to it blocks the host for the length of the copy, which orders the
-        // reuse of a slot by itself (the host passes the downloads of group g before it issues the uploads of group
-        // g + 2) and costs nothing as long as the next group's kernels are enqueued first.
+        // of their own.  Every pair has its device images twice (slot g & 1) on the engine that runs it, with page-locked
+        // staging beside them (copies from / to pageable memory would block the host until the GPU gets round to them --
+        // and a chained sweep launch holds every CU for its whole length), and four events:
+        //   in:   images uploaded   -- the pair's cost stage waits for this one only: the first kernels start when the first
+        //                              pair has arrived, not the whole group
+        //   used: images consumed   -- the upload of group g + 2 into the same slot waits for it
+        //   out:  last kernel done  -- the pair's download waits for this one only (the epilogues of a group run three at a
+        //                              time, so maps leave while the pairs behind them are still being finished)
+        //   dl:   map in the staging buffer -- the host copies it to the caller's array; passed before the slot is reused
+        // The host copies caller -> staging -> caller with a few threads (one thread moves about 10 GB/s; 17 4K maps are 282 MB).
+        // The XYZ images (99.5 MB each) go straight to the caller's memory: staging them would pin gigabytes.
         BatchGuard guard{e};
         int cap = 1;
-        if ((rc = prepare_group(e, N, H, W, pl, &cap))) return rc;
+        const size_t slot_bytes = 2 * (2 * npx + npx * 2 + (xyz_out ? npx * 16 : 0));
+        if ((rc = prepare_group(e, N, H, W, pl, &cap, slot_bytes))) return rc;
         if (cap >= 2) {
             if (!e->chain_err.p) {
                 if ((rc = e->chain_err.ensure(16))) return rc;
@@ -1928,26 +1972,33 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
                 sgm_engine *q = eng[k] = k == 0 ? e : e->group[k - 1];
                 for (int sl = 0; sl < (ngroups > 1 ? 2 : 1); sl++) {
                     if ((rc = q->io[sl][0].ensure(npx)) || (rc = q->io[sl][1].ensure(npx)) || (rc = q->io[sl][2].ensure(npx * 2))) return rc;
+                    if ((rc = q->pin_io[sl][0].ensure(npx)) || (rc = q->pin_io[sl][1].ensure(npx)) || (rc = q->pin_io[sl][2].ensure(npx * 2))) return rc;
                     if (xyz_out && ((rc = q->io[sl][3].ensure(npx * 4)) || (rc = q->io[sl][4].ensure(npx * 12)))) return rc;
-                    if (!q->ev_io_in[sl]) HIP_TRY(hipEventCreateWithFlags(&q->ev_io_in[sl], hipEventDisableTiming));
-                    if (!q->ev_io_out[sl]) HIP_TRY(hipEventCreateWithFlags(&q->ev_io_out[sl], hipEventDisableTiming));
+                    for (hipEvent_t *ev : {&q->ev_io_in[sl], &q->ev_io_used[sl], &q->ev_io_out[sl], &q->ev_io_dl[sl]})
+                        if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
                 }
             }
             std::vector<const void *> dl(per), dr(per);
             std::vector<void *> dd(per), df(per), dx(per);
-            std::vector<hipEvent_t> evi(per), evo(per);
+            std::vector<hipEvent_t> evi(per), evu(per), evo(per);
             auto upload = [&](int gi) -> int {     // images of group gi -> slot gi & 1, pair by pair
                 const int sl = gi & 1, i0 = gi * per, n = std::min(N - i0, per);
                 for (int k = 0; k < n; k++) {
                     sgm_engine *q = eng[k];
                     const size_t i = (size_t)(i0 + k);
-                    HIP_TRY(hipMemcpyAsync(q->io[sl][0].p, lefts + i * npx, npx, hipMemcpyHostToDevice, e->copy_in));
-                    HIP_TRY(hipMemcpyAsync(q->io[sl][1].p, rights + i * npx, npx, hipMemcpyHostToDevice, e->copy_in));
+                    if (gi >= 2) {
+                        HIP_TRY(hipEventSynchronize(q->ev_io_in[sl]));                 // the staging buffers: their last upload has left them (long ago)
+                        HIP_TRY(hipStreamWaitEvent(e->copy_in, q->ev_io_used[sl], 0));  // the device images: group gi - 2 has read them
+                    }
+                    host_copy(q->pin_io[sl][0].p, lefts + i * npx, npx);
+                    host_copy(q->pin_io[sl][1].p, rights + i * npx, npx);
+                    HIP_TRY(hipMemcpyAsync(q->io[sl][0].p, q->pin_io[sl][0].p, npx, hipMemcpyHostToDevice, e->copy_in));
+                    HIP_TRY(hipMemcpyAsync(q->io[sl][1].p, q->pin_io[sl][1].p, npx, hipMemcpyHostToDevice, e->copy_in));
                     HIP_TRY(hipEventRecord(q->ev_io_in[sl], e->copy_in));
                 }
                 return SGM_OK;
             };
-            auto compute = [&](int gi) -> int {
+            auto compute = [&](int gi) -> int {    // kernels of group gi, and -- behind each pair's last one -- its download
                 const int sl = gi & 1, i0 = gi * per, n = std::min(N - i0, per);
                 for (int k = 0; k < n; k++) {
                     sgm_engine *q = eng[k];
@@ -1958,26 +2009,36 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
                     df[k] = xyz_out ? q->io[sl][3].p : nullptr;
                     dx[k] = xyz_out ? q->io[sl][4].p : nullptr;
                     evi[k] = q->ev_io_in[sl];
+                    evu[k] = q->ev_io_used[sl];
                     evo[k] = q->ev_io_out[sl];
                 }
                 if (n == 1) {   // (a last group of one pair: the plain entry on e, behind its upload)
                     HIP_TRY(hipStreamWaitEvent(e->stream, evi[0], 0));
                     int r2 = sgm_pipeline_device(e, dl[0], dr[0], H, W, W, Q16, dd[0], df[0], dx[0]);
                     if (r2) return r2;
+                    HIP_TRY(hipEventRecord(evu[0], e->stream));
                     HIP_TRY(hipEventRecord(evo[0], e->stream));
-                    return SGM_OK;
+                } else {
+                    int r2 = run_group(e, eng.data(), n, pl, dl.data(), dr.data(), H, W, W, Q16, dd.data(), xyz_out ? df.data() : nullptr,
+                                       xyz_out ? dx.data() : nullptr, evi.data(), evu.data(), evo.data());
+                    if (r2) return r2;
                 }
-                return run_group(e, eng.data(), n, pl, dl.data(), dr.data(), H, W, W, Q16, dd.data(), xyz_out ? df.data() : nullptr,
-                                 xyz_out ? dx.data() : nullptr, evi.data(), evo.data());
+                for (int k = 0; k < n; k++) {
+                    sgm_engine *q = eng[k];
+                    HIP_TRY(hipStreamWaitEvent(e->copy_out, q->ev_io_out[sl], 0));
+                    HIP_TRY(hipMemcpyAsync(q->pin_io[sl][2].p, q->io[sl][2].p, npx * 2, hipMemcpyDeviceToHost, e->copy_out));
+                    HIP_TRY(hipEventRecord(q->ev_io_dl[sl], e->copy_out));
+                }
+                return SGM_OK;
             };
-            auto download = [&](int gi) -> int {   // maps (and XYZ) of group gi, each as soon as its pair is done
+            auto finish = [&](int gi) -> int {     // maps (and XYZ) of group gi into the caller's arrays
                 const int sl = gi & 1, i0 = gi * per, n = std::min(N - i0, per);
                 for (int k = 0; k < n; k++) {
                     sgm_engine *q = eng[k];
                     const size_t i = (size_t)(i0 + k);
-                    HIP_TRY(hipStreamWaitEvent(e->copy_out, q->ev_io_out[sl], 0));
-                    HIP_TRY(hipMemcpyAsync(disps_out + i * npx, q->io[sl][2].p, npx * 2, hipMemcpyDeviceToHost, e->copy_out));
-                    if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out + i * npx * 3, q->io[sl][4].p, npx * 12, hipMemcpyDeviceToHost, e->copy_out));
+                    HIP_TRY(hipEventSynchronize(q->ev_io_dl[sl]));
+                    host_copy(disps_out + i * npx, q->pin_io[sl][2].p, npx * 2);
+                    if (xyz_out) HIP_TRY(hipMemcpy(xyz_out + i * npx * 3, q->io[sl][4].p, npx * 12, hipMemcpyDeviceToHost));
                 }
                 return SGM_OK;
             };
@@ -1985,10 +2046,9 @@ int sgm_compute_batch(sgm_engine *e, int N, const uint8_t *lefts, const uint8_t 
             for (int gi = 0; gi < ngroups; gi++) {
                 if ((rc = compute(gi))) return rc;
                 if (gi + 1 < ngroups && (rc = upload(gi + 1))) return rc;     // beside the kernels of group gi
-                if (gi > 0 && (rc = download(gi - 1))) return rc;              // (done since the kernels of gi were enqueued behind it)
+                if (gi > 0 && (rc = finish(gi - 1))) return rc;                // (its slot's maps are rewritten by group gi + 1, enqueued after this)
             }
-            if ((rc = download(ngroups - 1))) return rc;
-            HIP_TRY(hipStreamSynchronize(e->copy_out));
+            if ((rc = finish(ngroups - 1))) return rc;
             HIP_TRY(hipStreamSynchronize(e->stream));
             guard.ok = true;
             return check_chain(e);

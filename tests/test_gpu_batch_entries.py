@@ -171,8 +171,12 @@ def test_host_entry_in_throughput_mode_with_groups_in_flight(N, gmax, with_q):
     eng.set_option(_lib.SGM_OPT_SCHEDULE, 2)
     eng.set_option(_lib.SGM_OPT_SWEEP_ROWS, 5)
     eng.set_option(_lib.SGM_OPT_GROUP_MAX, gmax)
+    res = None
     for rep in range(2):
-        res = eng.compute_batch_host(L, R, Q if with_q else None)
+        if res is not None:      # the second call fills the first call's arrays again (out=)
+            for a in (res if with_q else (res,)):
+                a[...] = 0
+        res = eng.compute_batch_host(L, R, Q if with_q else None, out=res)
         disps, xyz = res if with_q else (res, None)
         for i, (a, b) in enumerate(pairs):
             want = O.sgbm_compute(a, b, **p)

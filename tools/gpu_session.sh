@@ -1,7 +1,11 @@
+# one lease: the round's new tests first (fail fast), then the whole GPU suite, then the bench lines
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_paths.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_chain.py -x -q > gpurun_out/session_pytest.log 2>&1; rc=$?
-tail -3 gpurun_out/session_pytest.log
+timeout -k 10 600 python -m pytest tests/test_gpu_guard.py tests/test_gpu_batch_entries.py -x -q -m gpu > gpurun_out/session_new.log 2>&1; rc=$?
+tail -15 gpurun_out/session_new.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/session_pytest.log 2>&1; rc=$?
+tail -5 gpurun_out/session_pytest.log
 [ $rc -eq 0 ] || exit $rc
 run() {
   echo "== $*"
@@ -15,4 +19,4 @@ for l in sys.stdin:
 print(' | '.join(o))
 "
 }
-run c3c5x12 8 && run c3c5 20 && run c2 20 && run c4t 10 && run c1 40 && run c1t 10
+run c3c5x17 8 && run c3c5x12 8 && run c3c5 20 && run c4t 10 && run c1t 10
