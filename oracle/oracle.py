@@ -87,13 +87,39 @@ def geometry(p: Params, W: int):
     return a.value, b.value  # minX1, W1
 
 
-def sgbm_compute(left: np.ndarray, right: np.ndarray, taps: bool = False, **kw):
+def workspace(H: int, W: int, **kw):
+    """Volumes a caller keeps between calls of sgbm_compute(..., workspace=ws) on frames of one shape: MODE_HH holds the
+    block cost and the aggregated cost of the whole frame (upstream does too), and allocating + first touching them is most
+    of a short call (bench.py's frame-parallel CPU baseline runs one such call per thread)."""
+    p = kw.pop("params", None) or make_params(**kw)
+    _, W1 = geometry(p, W)
+    shape = (H, max(W1, 0), p.numDisparities)
+    return dict(C=np.empty(shape, np.int16), S=np.empty(shape, np.int16))
+
+
+def sgbm_compute(left: np.ndarray, right: np.ndarray, taps: bool = False, workspace=None, **kw):
     """stereo.compute(left, right) of main.ipynb:668 -> int16 (H, W).
 
     With taps=True also returns a dict with C, S, disp_raw, disp_median and the headroom record;
     taps="light" leaves out the two volumes (full-size frames: 4 GB each at 4K, D=256).
+    workspace (from workspace()): the two volumes are the caller's, reused call after call; returns the map only.
     """
     p = kw.pop("params", None) or make_params(**kw)
+    if workspace is not None:
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        H, W = left.shape
+        _, W1 = geometry(p, W)
+        assert workspace["C"].shape == (H, max(W1, 0), p.numDisparities) == workspace["S"].shape
+        disp = np.empty((H, W), np.int16)
+        t = Taps()
+        if W1 > 0:
+            t.C = workspace["C"].ctypes.data
+            t.S = workspace["S"].ctypes.data
+        rc = lib().oracle_sgbm_compute(C.byref(p), left.ctypes.data, right.ctypes.data, H, W, left.strides[0], disp.ctypes.data, C.byref(t))
+        if rc != 0:
+            raise ValueError(f"oracle_sgbm_compute failed rc={rc}")
+        return disp
     left = np.ascontiguousarray(left, dtype=np.uint8)
     right = np.ascontiguousarray(right, dtype=np.uint8)
     assert left.ndim == 2 and left.shape == right.shape

@@ -371,8 +371,9 @@ __device__ __forceinline__ void sweep_compute_wave(const Geom &g, const SweepArg
     L0.fill(init);
     ShiftRegs sr0, srA, srB, srC;
     // headroom record (sgm_get_headroom): largest min_d L_r(p, d) of the row, all four directions.
-    // The reductions return splats {m, m}, whose unsigned 32-bit maximum is the splat of the
-    // maximum -- four scalar instructions per pixel, nothing added to the vector stream.
+    // The reduction leaves the four splats {m, m} in the four rows of one register; its per-lane running maximum
+    // (unsigned 32-bit maximum of splats = splat of the maximum) is ONE instruction per pixel -- round 3 took four
+    // s_max_u32 on the four v_readlane results: every instruction of any kind costs a wave one issue slot here.
     uint32_t hm = 0;
     Pack<NP> cA[PB], cB[PB], sA[PB], sB[PB];
     // this row of C and S as buffer resources: one constant per-lane byte offset register plus a
@@ -391,11 +392,33 @@ __device__ __forceinline__ void sweep_compute_wave(const Geom &g, const SweepArg
     const int b0 = a.xdir > 0 ? 0 : (W1 - 1) * D * 2;
     const int wk = a.xdir > 0 ? 1 : -1;
     uint2 *const wrow = a.wta + (int64_t)y * g.W + g.minX1 + (a.xdir > 0 ? 0 : W1 - 1);
+    // Full waves (D = 128 NP): a pixel is PXB = 256 NP bytes, a block of PB pixels spans at most 3.8 KB -- inside the 12-bit
+    // immediate offset of a buffer instruction.  The pixels of a FULL block are then addressed as ONE scalar offset per
+    // block (its lowest address) + an immediate per pixel, instead of one SGPR offset per pixel of the two blocks in flight:
+    // round 3's k_sweep_chain held 24 such offsets, ran out of SGPRs (142 spills) and rebuilt them with s_mul_i32 + s_add_i32
+    // in the hot loop.  The direction of the sweep is the pass (the engine runs SWEEP_FIRST top-down / left to right and
+    // the second pass the other way round: sgm_engine.hip asserts it), so the immediates are compile-time constants.
+    constexpr bool IMM = !PARTIAL;
+    constexpr int XD = MODE == SWEEP_FIRST ? 1 : -1;
+    constexpr int PXB = 256 * NP;
+    static_assert((PB - 1) * PXB + 8 < 4096, "a block's pixels must fit the immediate offset field");
+    // lowest byte offset of the block of pixels k0 .. k0 + PB - 1 (all of them inside the row), and pixel u's distance from it
+    auto block_base = [&](int k0) { return XD > 0 ? k0 * PXB : (W1 - PB - k0) * PXB; };
+    auto px_imm = [](int u) { return XD > 0 ? u * PXB : (PB - 1 - u) * PXB; };
 
     // FULL blocks (all but the last of a row) are straight-line code without guards, so that the
     // scheduler can interleave the independent chains of the PPS pixels of a step
     auto load_block_t = [&](auto full_c, Pack<NP> *cb, Pack<NP> *sb, int k0) {
         constexpr bool FULL = decltype(full_c)::value;
+        if constexpr (FULL && IMM) {
+            const int sbase = block_base(k0);
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                buf_load<NP, LDAUX>(cb[u], Crow, voff + px_imm(u), sbase);
+                if (READS_S) buf_load<NP, LDAUX>(sb[u], Srow, voff + px_imm(u), sbase);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < PB; u++) {
             if (FULL || k0 + u < W1) {
@@ -406,8 +429,9 @@ __device__ __forceinline__ void sweep_compute_wave(const Geom &g, const SweepArg
         }
     };
     // one pixel: four recurrences (minima reduced two directions at a time), hand-off, S, WTA
+    // (vo, so): where this pixel's S goes -- per-lane offset (+ immediate) and scalar offset
     auto pixel = [&](const Pack<NP> &Cp, const Pack<NP> &Sp, const Pack<NP> &QA, const Pack<NP> &QB,
-                     const Pack<NP> &QC, int u, int k) {
+                     const Pack<NP> &QC, int u, int vo, int so) {
         Pack<NP> N0, NA, NB, NC;
         uint32_t r0, rA, rB, rC;
         path_elem<NP, PARTIAL>(Cp, L0, P1s, P2s, active, N0, r0, sr0);
@@ -415,11 +439,9 @@ __device__ __forceinline__ void sweep_compute_wave(const Geom &g, const SweepArg
         path_elem<NP, PARTIAL>(Cp, QB, P1s, P2s, active, NB, rB, srB);
         path_elem<NP, PARTIAL>(Cp, QC, P1s, P2s, active, NC, rC, srC);
         uint32_t ms[4];  // {m, m} of the directions 0, A, B, C
-        wave_min4_splat(r0, rA, rB, rC, ms);
-        smax_u32(hm, ms[0]);
-        smax_u32(hm, ms[1]);
-        smax_u32(hm, ms[2]);
-        smax_u32(hm, ms[3]);
+        uint32_t rows;
+        wave_min4_splat(r0, rA, rB, rC, ms, rows);
+        hm = max(hm, rows);
         Pack<NP> LA, LB, LC;
         path_normalise_splat<NP, PARTIAL>(N0, ms[0], active, L0);
         path_normalise_splat<NP, PARTIAL>(NA, ms[1], active, LA);
@@ -436,12 +458,13 @@ __device__ __forceinline__ void sweep_compute_wave(const Geom &g, const SweepArg
             if (READS_S) v = pk_adds_s(v, Sp.r[i]);
             Sn.r[i] = v;
         }
-        if (!PARTIAL || active) buf_store<NP>(Sn, Sst, voff, b0 + k * bk);
+        if (!PARTIAL || active) buf_store<NP>(Sn, Sst, vo, so);
         return Sn;
     };
 
     auto compute_block_t = [&](auto full_c, Pack<NP> *cb, Pack<NP> *sb, int k0) {  // k0 % PB == 0
         constexpr bool FULL = decltype(full_c)::value;
+        const int sbase = (FULL && IMM) ? block_base(k0) : 0;
 #pragma unroll
         for (int u0 = 0; u0 < PB; u0 += PPS) {
             if (FULL || k0 + u0 < W1) {
@@ -457,7 +480,8 @@ __device__ __forceinline__ void sweep_compute_wave(const Geom &g, const SweepArg
 #pragma unroll
                 for (int p = 0; p < PPS; p++) {
                     const int u = u0 + p;
-                    if (FULL || k0 + u < W1) Sn[p] = pixel(cb[u], sb[u], QA[p], QB[p], QC[p], u, k0 + u);
+                    if constexpr (FULL && IMM) Sn[p] = pixel(cb[u], sb[u], QA[p], QB[p], QC[p], u, voff + px_imm(u), sbase);
+                    else if (FULL || k0 + u < W1) Sn[p] = pixel(cb[u], sb[u], QA[p], QB[p], QC[p], u, voff, b0 + (k0 + u) * bk);
                 }
                 if (MODE == SWEEP_LAST) {  // winner-take-all of the step's pixels, chains interleaved
                     if (FULL || k0 + u0 + PPS <= W1) {
@@ -497,7 +521,10 @@ __device__ __forceinline__ void sweep_compute_wave(const Geom &g, const SweepArg
             compute_block_t(part, cB, sB, k0 + PB);
         }
     }
-    if (g.hr && lane == 0) headroom_raise(g.hr + 1, hm & 0xffffu);
+    {
+        const uint32_t hmax = wave_max_u32(hm) & 0xffffu;
+        if (g.hr && lane == 0) headroom_raise(g.hr + 1, hmax);
+    }
     // one step after the last real pixel: the virtual pixel W1 (start state) for the row below
     if (wave < R - 1) {
         sweep_write_start_state<NP>(mine, W1 % RING, init);

@@ -114,10 +114,14 @@ __device__ __forceinline__ uint32_t fold16_pair(uint32_t a, uint32_t b)
     const auto s = __builtin_amdgcn_permlane16_swap(a, b, false, false);
     return pk_min_s(s[0], s[1]);
 }
-__device__ __forceinline__ void wave_min4_splat(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t (&ms)[4])
+// `rows` (out): the register the four splats are read from -- every lane of row r holds its direction's {m, m}; callers
+// that only want the largest of many such minima (the headroom record) keep a per-lane running maximum of it (ONE vector
+// instruction per pixel; unsigned 32-bit order = order of the value, as above) instead of four scalar maxima.
+__device__ __forceinline__ void wave_min4_splat(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t (&ms)[4], uint32_t &rows)
 {
     // rows of 16 lanes after the two folds: directions 0, 2, 1, 3
     const uint32_t x = row_min_eq(fold_halves(fold16_pair(fold32_pair(r0, r1), fold32_pair(r2, r3))));
+    rows = x;
     ms[0] = __builtin_amdgcn_readlane(x, 0);
     ms[2] = __builtin_amdgcn_readlane(x, 16);
     ms[1] = __builtin_amdgcn_readlane(x, 32);

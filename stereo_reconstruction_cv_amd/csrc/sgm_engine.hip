@@ -452,8 +452,17 @@ static int launch_sweep_np(const Geom &g, const SweepArgs &a, int mode, int nban
     if (g.uniq < 100) return launch_sweep_one<NP, PARTIAL, SWEEP_LAST, true>(g, a, nbands, st);
     return launch_sweep_one<NP, PARTIAL, SWEEP_LAST, false>(g, a, nbands, st);
 }
+// the sweep kernels take the direction of the walk from the pass (kernels_sweep.h: XD): the first pass runs top-down and left
+// to right, every other pass the other way round
+static int check_sweep_direction(const SweepArgs &a, int mode)
+{
+    if ((mode == SWEEP_FIRST) != (a.xdir > 0) || a.xdir != a.ydir)
+        return set_err(SGM_ERR_INVALID_ARG, "internal: sweep mode %d with direction (%d, %d)", mode, a.xdir, a.ydir);
+    return SGM_OK;
+}
 static int launch_sweep(const Geom &g, const SweepArgs &a, int mode, int nbands, hipStream_t st)
 {
+    if (int rc = check_sweep_direction(a, mode)) return rc;
     const bool partial = g.D != 128 * g.NP;
     if (g.NP == 1) return partial ? launch_sweep_np<1, true>(g, a, mode, nbands, st) : launch_sweep_np<1, false>(g, a, mode, nbands, st);
     if (g.NP == 2) return partial ? launch_sweep_np<2, true>(g, a, mode, nbands, st) : launch_sweep_np<2, false>(g, a, mode, nbands, st);
@@ -477,6 +486,7 @@ static int launch_chain_np(const Geom &g, const SweepArgs &a, const ChainFrames 
 }
 static int launch_chain(const Geom &g, const SweepArgs &a, const ChainFrames &fr, int mode, int wgs, hipStream_t st)
 {
+    if (int rc = check_sweep_direction(a, mode)) return rc;
     const bool partial = g.D != 128 * g.NP;
     if (g.NP == 1) return partial ? launch_chain_np<1, true>(g, a, fr, mode, wgs, st) : launch_chain_np<1, false>(g, a, fr, mode, wgs, st);
     if (g.NP == 2) return partial ? launch_chain_np<2, true>(g, a, fr, mode, wgs, st) : launch_chain_np<2, false>(g, a, fr, mode, wgs, st);

@@ -167,3 +167,25 @@ def test_single_wave_kernels_keep_their_instruction_count():
     m = _largest_block_mix(text, "k_pixILi2E")                                    # four columns per iteration
     assert m["s_load_dwordx8"] == 1 and m["buffer_store_dword"] == 4, m
     assert sum(n for k, n in m.items() if k.startswith("v_")) <= 205, m
+
+
+def test_chained_sweep_keeps_the_plain_sweeps_instruction_stream():
+    """Round 4: the steady-state block of k_sweep_chain<2, false, .> -- 16 pixels of the
+    headline configuration -- had grown to 1 862 / 1 919 instructions against k_sweep's 1 784 / 1 829: 24 per-pixel scalar
+    offsets ran the kernel out of SGPRs and were rebuilt in the loop (18 s_mul_i32 + 25 s_add_i32).  Full blocks now address
+    their pixels with ONE scalar offset per block + immediates, and the headroom maximum is one vector maximum per pixel
+    instead of four s_max_u32.  What must stay: no multiplications and next to no scalar additions in the block, no SGPR
+    spill traffic beyond the reduction's own four v_readlane per pixel, and the block no longer than 1 830 instructions
+    in the first pass (1 890 in the second, which also loads S)."""
+    csrc = os.path.join(ROOT, "stereo_reconstruction_cv_amd", "csrc")
+    text = open(os.path.join(csrc, "sgm_engine.s")).read()
+    for mode, limit in ((0, 1830), (1, 1890)):
+        m = _largest_block_mix(text, f"k_sweep_chainILi2ELb0ELi{mode}E")
+        total = sum(m.values())
+        assert total <= limit, (mode, total)
+        assert m["s_mul_i32"] == 0 and m["s_add_i32"] + m["s_addk_i32"] <= 8, (mode, m)
+        assert m["v_readlane_b32"] == 64 and m["v_writelane_b32"] == 0 and m["s_max_u32"] == 0, (mode, m)
+        assert m["buffer_load_dwordx2"] == (16 if mode == 0 else 32) and m["buffer_store_dwordx2"] == 16, (mode, m)
+        plain = sum(_largest_block_mix(text, f"k_sweepILi2ELb0ELi{mode}ELb1E").values())
+        assert total <= plain + 70, (mode, total, plain)     # what is left: s_nop the scheduler pads a lone DPP chain with
+

@@ -1,6 +1,17 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_gpu_batch_entries.py tests/test_gpu_configs.py::test_c4_batch_1080p_d128_both_batch_entries -x -q -m gpu > gpurun_out/session_new.log 2>&1; rc=$?
-tail -5 gpurun_out/session_new.log
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/session_pytest.log 2>&1; rc=$?
+tail -5 gpurun_out/session_pytest.log
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 600 python tools/host_rate.py > gpurun_out/host_rate_r04b.txt 2>&1; tail -12 gpurun_out/host_rate_r04b.txt
+run() {
+  timeout -k 10 300 python bench.py --workload $1 --stages --no-cpu-baseline --no-latency-mode --steps ${2:-10} --warmup 3 2>&1 | python -c "
+import sys,json
+o=['$1']
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); o.append('ms/pair %.3f' % d['ms_per_pair'])
+    elif l.startswith('  ') and not l.startswith('  sum'): o.append(' '.join(l.split()[:2]))
+print(' | '.join(o))
+"
+}
+run c3c5x17 8 && run c3c5x24 6 && run c3c5x12 8 && run c3c5 20 && run c2 20 && run c4t 10 && run c1t 10 && run c5x17 8
