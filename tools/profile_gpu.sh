@@ -7,7 +7,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift
 WLS=${@:-c3c5x12}
 B="--no-cpu-baseline --no-latency-mode"
