@@ -6,10 +6,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 d = os.path.join(ROOT, "profiles", tag)
 pmc = json.load(open(os.path.join(d, "pmc_traffic.json")))["workloads"]
-order = ["default", "c3c5x18", "c3c5x16", "c3c5x14", "c3c5x12", "c3c5x6", "c3c5", "c3", "c3c5x2", "c3c5x3", "c5", "c5x12", "c2", "c4", "c4t", "c1", "c1x8", "c1t", "nb"]
+order = ["default", "c3c5x24", "c3c5x18", "c3c5x16", "c3c5x14", "c3c5x12", "c3c5x8", "c3c5x6", "c3c5", "c3", "c3c5x2", "c3c5x3", "c5", "c5x17", "c5x12", "c2", "c4", "c4t", "c1", "c1x8", "c1t", "nb"]
 print("| workload | pairs / step | schedule | ms / pair | pairs/s | Mdisp/s | floor GB | PMC traffic GB (V) | traffic / floor | time / floor at 6.29 TB/s | "
       "HBM GB/s (frac of 8 TB/s) | dominant kernel: achieved GB/s (frac), basis |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
