@@ -1,17 +1,15 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
+export SGM_ALLOW_WRONG_RESULTS=1
 run() {
-  timeout -k 10 300 python bench.py --no-cpu-baseline --no-latency-mode --steps 8 --warmup 3 "$@" 2>/dev/null | python -c "
-import sys,json,os
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-latency-mode --steps 20 --warmup 3 --workload c3c5 "$@" 2>/dev/null | python -c "
+import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print(os.environ.get('GPU_MAX_HW_QUEUES','default'), '$*', '-> ms/pair %.3f' % d['ms_per_pair'], {k: round(v,2) for k,v in d['stage_ms'].items() if v > 0.5})
+        d=json.loads(l); print('$*', '-> ms/pair %.3f' % d['ms_per_pair'], {k: round(v,2) for k,v in d['stage_ms'].items() if k.startswith('cost')})
 "
 }
-run --workload c3c5x17
-export GPU_MAX_HW_QUEUES=8
-run --workload c3c5x17
-export GPU_MAX_HW_QUEUES=16
-run --workload c3c5x17
-export GPU_MAX_HW_QUEUES=2
-run --workload c3c5x17
+run
+run --debug 262144
+run --debug 524288
+run --debug 1048576
+run --debug 131072
