@@ -1,15 +1,12 @@
 cd $GRAFT_REPO_ROOT
-export SGM_ALLOW_WRONG_RESULTS=1
-run() {
-  timeout -k 10 300 python bench.py --no-cpu-baseline --no-latency-mode --steps 20 --warmup 3 --workload c3c5 "$@" 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('$*', '-> ms/pair %.3f' % d['ms_per_pair'], {k: round(v,2) for k,v in d['stage_ms'].items() if k.startswith('cost')})
-"
-}
-run
-run --debug 262144
-run --debug 524288
-run --debug 1048576
-run --debug 131072
+mkdir -p gpurun_out
+timeout -k 10 1000 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu_r04.log 2>&1; rc=$?
+tail -5 gpurun_out/pytest_gpu_r04.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 600 python bench.py --stages > gpurun_out/bench_default_r04.json 2> gpurun_out/bench_default_r04_stages.txt; echo bench rc=$?
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_default_r04.json').read().strip().splitlines()[-1])
+print(d['ms_per_pair'], d['pairs_per_s'], d['roofline']['frac'], d['cpu_baseline']['all_threads']['value'], d['speedup_vs_cpu_all_threads'], d['latency_mode']['ms_per_pair'])
+PY
+python -c "import __graft_entry__ as g; g.smoke()"
