@@ -1691,6 +1691,7 @@ static int prepare_group(sgm_engine *e, int want, int H, int W, const Plan &pl, 
     if ((rc = prepare_pair_buffers(e, H, W, pl))) return rc;
     *n_out = 1;
     if (want > 1 && !e->ev_group) HIP_TRY(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
+    bool retried = false;
     for (int k = 1; k < want; k++) {
         const bool is_new = (int)e->group.size() < k;
         if (is_new) {
@@ -1718,6 +1719,20 @@ static int prepare_group(sgm_engine *e, int want, int H, int W, const Plan &pl, 
         if (rc == SGM_ERR_NOMEM) {
             release_buffers(q);   // (a half-sized engine would only hold memory the smaller group could use)
             q->H = q->W = 0;
+            // engines behind this one may still hold the buffers of an earlier, larger batch or another shape: give those
+            // back once and try this engine again before settling for a smaller group
+            bool freed = false;
+            for (size_t j = (size_t)k; j < e->group.size(); j++)
+                if (e->group[j]->cost.p || e->group[j]->aggr.p) {
+                    release_buffers(e->group[j]);
+                    e->group[j]->H = e->group[j]->W = 0;
+                    freed = true;
+                }
+            if (freed && !retried) {
+                retried = true;
+                k--;
+                continue;
+            }
             break;
         }
         if (rc) return rc;

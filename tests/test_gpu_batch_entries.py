@@ -156,6 +156,43 @@ def test_trim_gives_the_group_memory_back_and_the_engine_still_works():
         assert np.array_equal(dd[i].cpu().numpy(), wants[i % 2]), i
 
 
+def test_group_shrinks_to_what_device_memory_holds():
+    """Device memory is squeezed (torch tensors that are never touched) until only a few pairs of a batch of ten fit beside the
+    reserve the engine keeps free (4 GiB / 5 %): the call must not fail -- and must not die of a kernel launch that finds no
+    memory -- but cut the batch into smaller groups, every map still its own pair's; with the memory back, the same engine
+    takes the batch in one group again."""
+    import torch
+    from stereo_reconstruction_cv_amd import stereo as cv_
+    cv_.clear_engine_cache()
+    H, W, D, N = 540, 1920, 128, 10
+    p = U.params(D, 7, 0, 1, speckleWindowSize=30, speckleRange=2)
+    pairs = [synth.make_pair(H, W, D, 5800 + i)[:2] for i in range(2)]
+    wants = [O.sgbm_compute(a, b, **p) for a, b in pairs]
+    dl, dr, dd, _, _ = _resident([pairs[i % 2] for i in range(N)], H, W, False)
+    eng = Engine(p)
+    eng.set_option(_lib.SGM_OPT_SCHEDULE, 2)
+    torch.cuda.empty_cache()
+    free_b, total = torch.cuda.mem_get_info()
+    per_pair = 2 * 2 * H * (W - D) * D + 3 * (H // 12 + 1) * (W - D) * D * 2      # C + S + hand-off record
+    reserve = max(4 << 30, total // 20)
+    keep = reserve + 4 * per_pair                                                    # room for about four pairs beyond the reserve
+    hog = torch.empty((max(free_b - keep, 0),), dtype=torch.uint8, device="cuda") if free_b > keep else None
+    try:
+        eng.pipeline_batch_device(ptr(dl), ptr(dr), H, W, W, None, ptr(dd))
+        eng.synchronize()
+        for i in range(N):
+            assert np.array_equal(dd[i].cpu().numpy(), wants[i % 2]), i
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    for t in dd:
+        t.fill_(-7)
+    eng.pipeline_batch_device(ptr(dl), ptr(dr), H, W, W, None, ptr(dd))
+    eng.synchronize()
+    for i in range(N):
+        assert np.array_equal(dd[i].cpu().numpy(), wants[i % 2]), i
+
+
 @pytest.mark.parametrize("N,gmax,with_q", [(8, 3, True), (7, 4, False), (5, 0, True), (3, 2, False)])
 def test_host_entry_in_throughput_mode_with_groups_in_flight(N, gmax, with_q):
     """sgm_compute_batch with SGM_OPT_SCHEDULE = 2: host arrays in, host arrays out (cv2.imread -> compute,
